@@ -1,0 +1,143 @@
+// Host-side exact replay of the reference's ensemble + channel sampling on identical seeds
+// (generate_code BPF:1656-1761, channel_doped BPF:1547-1574, inizio_sim's perm_code reset
+// BPF:308-311, srandom BPF:2062).  glibc's random() (TYPE_3 additive feedback, stdlib/random_r.c)
+// is restated here so the stream does not depend on the host's libc.
+#include "common.h"
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct GlibcRandom {
+    int32_t r[31];
+    int f, b;
+
+    void seed(uint32_t s)
+    {
+        int32_t word = (int32_t)(s ? s : 1u);
+        r[0] = word;
+        for (int i = 1; i < 31; i++) {          // Park–Miller via Schrage
+            const long hi = word / 127773, lo = word % 127773;
+            word = (int32_t)(16807 * lo - 2836 * hi);
+            if (word < 0) word += 2147483647;
+            r[i] = word;
+        }
+        f = 3; b = 0;
+        for (int k = 0; k < 310; k++) next();
+    }
+    inline int32_t next()
+    {
+        const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        if (++f == 31) f = 0;
+        if (++b == 31) b = 0;
+        return (int32_t)(v >> 1);
+    }
+};
+
+// Opaque state blob: the generator followed by perm_code[cns_pos*dc].
+struct StateHeader {
+    GlibcRandom rng;
+    int32_t nsock;
+    int32_t pad;
+};
+
+inline int32_t *perm_of(void *state) { return reinterpret_cast<int32_t *>(static_cast<char *>(state) + sizeof(StateHeader)); }
+
+void draw_frame(const scldpc_code_params *p, StateHeader *st, int32_t *perm, double eps,
+                int ndoped, const int32_t *doped, int32_t *vn_adj, uint32_t *chan_bits,
+                std::vector<int32_t> &sock_cn)
+{
+    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, D = p->L + dv - 1;
+    const int n = scldpc::n_of(p), nw = scldpc::nw_of(p);
+    GlibcRandom &g = st->rng;
+    sock_cn.resize((size_t)D * S);
+    for (int pos = 0; pos < D; pos++) {
+        for (int i = 0; i < S; i++) {                              // BPF:1682-1688
+            const int pick = i + g.next() % (S - i);
+            const int32_t t = perm[i]; perm[i] = perm[pick]; perm[pick] = t;
+        }
+        int32_t *row = &sock_cn[(size_t)pos * S];
+        for (int i = 0; i < S; i++) row[i] = pos * p->cns_pos + perm[i] / dc;   // BPF:1693
+    }
+    for (int pos = 0; pos < p->L; pos++)                            // BPF:1703-1716
+        for (int t = 0; t < p->vns_pos; t++) {
+            int32_t *out = vn_adj + ((size_t)pos * p->vns_pos + t) * dv;
+            for (int i = 0; i < dv; i++) out[i] = sock_cn[(size_t)(pos + i) * S + dv * t + i];
+        }
+    memset(chan_bits, 0, sizeof(uint32_t) * (size_t)nw);
+    for (int j = 0; j < n; j++) {                                   // BPF:1552-1563, unif_ch BPF:370
+        const double u = (double)g.next() / 2147483647.0;
+        if (!(u >= eps)) chan_bits[j >> 5] |= 1u << (j & 31);
+    }
+    for (int d = 0; d < ndoped; d++)                                // BPF:1566-1573
+        for (int j = doped[d] * p->vns_pos; j < (doped[d] + 1) * p->vns_pos; j++)
+            chan_bits[j >> 5] &= ~(1u << (j & 31));
+}
+
+int check_doped(const scldpc_code_params *p, int ndoped, const int32_t *doped)
+{
+    if (ndoped < 0 || (ndoped > 0 && !doped))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "bad doped-position list");
+    for (int d = 0; d < ndoped; d++)
+        if (doped[d] < 0 || doped[d] >= p->L)
+            return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "doped position %d outside [0,%d)", doped[d], p->L);
+    return SCLDPC_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t scldpc_glibc_state_bytes(const scldpc_code_params *p)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    return (int64_t)sizeof(StateHeader) + 4ll * p->cns_pos * p->dc;
+}
+
+extern "C" int scldpc_glibc_state_reset_perm(const scldpc_code_params *p, void *state)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (!state) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "null state");
+    int32_t *perm = perm_of(state);
+    for (int i = 0; i < p->cns_pos * p->dc; i++) perm[i] = i;       // BPF:308-311
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_glibc_state_init(const scldpc_code_params *p, uint32_t seed, void *state)
+{
+    if (int rc = scldpc_glibc_state_reset_perm(p, state)) return rc;
+    StateHeader *st = static_cast<StateHeader *>(state);
+    st->rng.seed(seed);
+    st->nsock = p->cns_pos * p->dc;
+    st->pad = 0;
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_sample_glibc_next_host(const scldpc_code_params *p, void *state, double eps,
+                                             int32_t ndoped, const int32_t *doped_positions, int32_t nframes,
+                                             int32_t *vn_adj, uint32_t *chan_bits)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (int rc = check_doped(p, ndoped, doped_positions)) return rc;
+    if (!state || nframes < 0 || (nframes > 0 && (!vn_adj || !chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sample_glibc_next_host: null buffer or negative nframes");
+    StateHeader *st = static_cast<StateHeader *>(state);
+    if (st->nsock != p->cns_pos * p->dc)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "state blob was initialised for a different ensemble");
+    const size_t adj_stride = (size_t)scldpc::n_of(p) * p->dv, ch_stride = (size_t)scldpc::nw_of(p);
+    std::vector<int32_t> sock_cn;
+    for (int f = 0; f < nframes; f++)
+        draw_frame(p, st, perm_of(state), eps, ndoped, doped_positions,
+                   vn_adj + f * adj_stride, chan_bits + f * ch_stride, sock_cn);
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_sample_glibc_host(const scldpc_code_params *p, uint32_t seed, double eps,
+                                        int32_t ndoped, const int32_t *doped_positions,
+                                        int32_t *vn_adj, uint32_t *chan_bits)
+{
+    const int64_t bytes = scldpc_glibc_state_bytes(p);
+    if (bytes < 0) return (int)bytes;
+    std::vector<char> state((size_t)bytes);
+    if (int rc = scldpc_glibc_state_init(p, seed, state.data())) return rc;
+    return scldpc_sample_glibc_next_host(p, state.data(), eps, ndoped, doped_positions, 1, vn_adj, chan_bits);
+}

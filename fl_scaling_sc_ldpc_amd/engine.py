@@ -1,0 +1,163 @@
+"""Thin host layer over the C-ABI: device buffers (torch, plumbing only) + kernel launches.
+
+Everything that computes runs inside libscldpc_hip.so; this module only owns memory and streams.
+Reference routines replaced (see include/scldpc.h for line citations): generate_code /
+channel_doped (sampling), decodeBP / decodeBP_SW (decoding), plr_computation / willIstop (run
+accumulation).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CodeParams, NCOUNTERS, NRUN, COUNTER_NAMES, RUN_NAMES, ScldpcError, check, lib  # noqa: F401
+
+
+def make_params(dv=4, dc=8, L=50, N=1000):
+    """(dv, dc, L, N) as in BASELINE.json: N = VNs per position (Def_VNsPos, Python's M);
+    cns_pos = N*dv/dc (Def_M)."""
+    if (N * dv) % dc:
+        raise ValueError(f"N*dv must be divisible by dc (N={N}, dv={dv}, dc={dc})")
+    return CodeParams(dv, dc, L, N * dv // dc, N)
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise ScldpcError("no HIP device visible: the decoders run only on the GPU (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling
+# ------------------------------------------------------------------------------------------------
+def sample_glibc_trials(p, seeds, eps, doped=()):
+    """Self-contained trials exactly as the reference draws them after `inizio_sim(); srandom(seed)`.
+    Returns host arrays vn_adj int32 [T,n,dv], chan_bits uint32 [T,nw]."""
+    seeds = np.asarray(seeds, dtype=np.uint32).reshape(-1)
+    T = seeds.size
+    vn_adj = np.empty((T, p.n, p.dv), dtype=np.int32)
+    chan = np.empty((T, p.nw), dtype=np.uint32)
+    darr, dptr = _lib.doped_array(doped)
+    for t in range(T):
+        check(lib().scldpc_sample_glibc_host(C.byref(p), int(seeds[t]), float(eps), darr.size, dptr,
+                                             vn_adj[t].ctypes.data, chan[t].ctypes.data))
+    return vn_adj, chan
+
+
+class GlibcRun:
+    """One reference run: a single srandom(seed), frames drawn back to back with perm_code and the
+    random() stream carried over (main_terminated, BPF:2057-2131)."""
+
+    def __init__(self, p, seed):
+        self.p = p
+        nbytes = lib().scldpc_glibc_state_bytes(C.byref(p))
+        if nbytes < 0:
+            check(int(nbytes))
+        self._state = np.zeros(nbytes, dtype=np.uint8)
+        check(lib().scldpc_glibc_state_init(C.byref(p), int(seed) & 0xFFFFFFFF, self._state.ctypes.data))
+
+    def new_point(self):
+        """inizio_sim(): perm_code := identity at the start of every ε point (BPF:308-311)."""
+        check(lib().scldpc_glibc_state_reset_perm(C.byref(self.p), self._state.ctypes.data))
+
+    def next_frames(self, nframes, eps, doped=()):
+        p = self.p
+        vn_adj = np.empty((nframes, p.n, p.dv), dtype=np.int32)
+        chan = np.empty((nframes, p.nw), dtype=np.uint32)
+        darr, dptr = _lib.doped_array(doped)
+        check(lib().scldpc_sample_glibc_next_host(C.byref(p), self._state.ctypes.data, float(eps), darr.size, dptr,
+                                                  nframes, vn_adj.ctypes.data, chan.ctypes.data))
+        return vn_adj, chan
+
+
+def to_device(vn_adj, chan, device="cuda:0"):
+    _require_gpu()
+    d_adj = torch.from_numpy(np.ascontiguousarray(vn_adj, dtype=np.int32)).to(device)
+    d_ch = torch.from_numpy(np.ascontiguousarray(chan).view(np.int32)).to(device)
+    return d_adj, d_ch
+
+
+def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None):
+    """Throughput-mode sampling on the device (counter-based; see scldpc_sample_philox_device)."""
+    _require_gpu()
+    if out is None:
+        d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int32, device=device)
+        d_ch = torch.empty((ntrials, p.nw), dtype=torch.int32, device=device)
+    else:
+        d_adj, d_ch = out
+    darr, dptr = _lib.doped_array(doped)
+    check(lib().scldpc_sample_philox_device(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps),
+                                            darr.size, dptr, d_adj.data_ptr(), d_ch.data_ptr(),
+                                            _stream_ptr(d_adj.device)))
+    return d_adj, d_ch
+
+
+# ------------------------------------------------------------------------------------------------
+# decoding
+# ------------------------------------------------------------------------------------------------
+def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=False, counters=None):
+    """decodeBP for a batch resident on the device.  Returns dict of device tensors:
+    counters int32 [T,8] (+ rows int32 [T,rows_cap,3], erased int32 [T,nw] when asked)."""
+    _require_gpu()
+    T = d_adj.shape[0]
+    assert d_adj.is_cuda and d_adj.dtype == torch.int32 and d_adj.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    assert tuple(d_adj.shape[1:]) == (p.n, p.dv) and tuple(d_chan.shape) == (T, p.nw)
+    dev = d_adj.device
+    if counters is None:
+        counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+    rows = torch.zeros((T, rows_cap, 3), dtype=torch.int32, device=dev) if rows_cap > 0 else None
+    erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    check(lib().scldpc_full_bp_device(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(max_it),
+                                      1 if is_term else 0, counters.data_ptr(),
+                                      rows.data_ptr() if rows is not None else None, int(rows_cap),
+                                      erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    return {"counters": counters, "rows": rows, "erased": erased}
+
+
+def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None):
+    """decodeBP_SW (square window, BPW:628-912) for a batch resident on the device."""
+    _require_gpu()
+    T = d_adj.shape[0]
+    assert d_adj.is_cuda and d_adj.dtype == torch.int32 and d_adj.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    dev = d_adj.device
+    if counters is None:
+        counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+    erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    check(lib().scldpc_sw_bp_device(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it),
+                                    int(init_it), counters.data_ptr(),
+                                    erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    return {"counters": counters, "erased": erased}
+
+
+def accumulate_run(d_counters, d_run, stop_frame_err=0):
+    """plr_computation + willIstop in trial order; d_run int64 [NRUN] accumulated in place."""
+    check(lib().scldpc_accumulate_run_device(d_counters.shape[0], d_counters.data_ptr(), int(stop_frame_err),
+                                             d_run.data_ptr(), _stream_ptr(d_counters.device)))
+    return d_run
+
+
+def new_run(device="cuda:0"):
+    return torch.zeros(NRUN, dtype=torch.int64, device=device)
+
+
+def unpack_bits(words, n):
+    """uint32/int32 words [.., nw] → uint8 [.., n] (host)."""
+    w = np.ascontiguousarray(words).view(np.uint32)
+    bits = np.unpackbits(w.view(np.uint8).reshape(*w.shape[:-1], -1), axis=-1, bitorder="little")
+    return bits[..., :n]
+
+
+def pack_bits(bits):
+    """uint8 [.., n] → uint32 words [.., nw] (host)."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    n = bits.shape[-1]
+    pad = (-n) % 32
+    if pad:
+        bits = np.concatenate([bits, np.zeros(bits.shape[:-1] + (pad,), np.uint8)], axis=-1)
+    return np.packbits(bits, axis=-1, bitorder="little").view(np.uint32)

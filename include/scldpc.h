@@ -1,0 +1,150 @@
+/*
+ * scldpc.h — C-ABI of libscldpc_hip.so: MI355X (gfx950) Monte-Carlo BEC decoding of random
+ * SC-LDPC ensembles.  Drop-in for the hot path of rsokolovskii/fl_scaling_sc_ldpc's
+ * simulators_sc_ldpc/{bp_decoding,peeling_decoding}.
+ *
+ * The reference has no FFI: its hot path sits behind process argv + output files and two Python
+ * function signatures.  The entry points below are what a binding for that path
+ * would call; each cites the reference routine it replaces.  Abbreviations:
+ *   BPF = simulators_sc_ldpc/bp_decoding/SC_LDPC_Simulator_BPDecoder_BEC_full_BP_LimIter_OlmosRandomEnsemble.c
+ *   BPW = …/SC_LDPC_Simulator_BPDecoder_BEC_SlidingWindow_LimIter_OlmosRandomEnsemble.c
+ *   BPT = …/trajectories_SC_LDPC_Simulator_BPDecoder_BEC_full_BP_OlmosRandomEnsemble.c
+ *   PD  = simulators_sc_ldpc/peeling_decoding/peeling_decoding.py
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, `int` status return (0 = OK,
+ * negative = error, text via scldpc_last_error()), no globals shared between calls.  Pointers
+ * named d_* are DEVICE pointers (HIP); `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Device entry points only enqueue work; they never synchronise.
+ *
+ * Data layout (one "trial" = one sampled code + one channel realisation = one reference "frame"):
+ *   vn_adj   int32 [ntrials][n][dv]       CN index of edge i of VN j   (VNdegree[j][1+i], BPF:87)
+ *   chan     uint32[ntrials][nw]          bit (j&31) of word j>>5 = LLRsChannel[j] (1 = erased, BPF:91);
+ *                                         nw = (n+31)/32, padding bits of the last word ignored
+ *   counters int32 [ntrials][SCLDPC_NCOUNTERS]   see enum below
+ *   rows     int32 [ntrials][rows_cap][3] per-iteration (deg_1_iter, recovered, first_erased/VNsPos) — BPT:988,1051
+ *   erased   uint32[ntrials][nw]          VNerased after decoding, bit-packed like chan
+ * with n = vns_pos*L VNs, nk = (L+dv-1)*cns_pos CNs (terminated chain, BPF:30,37).
+ */
+#ifndef SCLDPC_H
+#define SCLDPC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCLDPC_ABI_VERSION 1
+
+enum {
+    SCLDPC_OK = 0,
+    SCLDPC_ERR_BAD_ARG = -1,
+    SCLDPC_ERR_TOO_LARGE = -2,      /* ensemble does not fit the kernel's LDS budget */
+    SCLDPC_ERR_HIP = -3,            /* a HIP runtime call failed                     */
+    SCLDPC_ERR_NO_DEVICE = -4
+};
+
+/* Ensemble geometry — the compile-time #defines of BPF:22-37 as run-time parameters.
+ * Naming trap: cns_pos = Def_M = Def_CNsPos; vns_pos = Def_VNsPos = "N" of the papers = Python's M (PD:18). */
+typedef struct scldpc_code_params {
+    int32_t dv;        /* Def_dv  */
+    int32_t dc;        /* Def_dc  */
+    int32_t L;         /* Def_L   */
+    int32_t cns_pos;   /* Def_CNsPos */
+    int32_t vns_pos;   /* Def_VNsPos; dv*vns_pos must equal dc*cns_pos */
+} scldpc_code_params;
+
+/* Per-trial outputs of the decoders. */
+enum {
+    SCLDPC_C_NUM_ERASURES = 0,       /* return value of decodeBP / decodeBP_SW (BPF:1138, BPW:910) */
+    SCLDPC_C_NUM_BLOCKS_ERR = 1,     /* *num_blocks_err      (BPF:1123-1125, BPW:843-844)           */
+    SCLDPC_C_NUM_ERASURES_EXP = 2,   /* *num_erasures_exp    (BPF:1126-1132, BPW:903-907)           */
+    SCLDPC_C_NUM_BLOCKS_ERR_EXP = 3, /* *num_blocks_err_exp                                          */
+    SCLDPC_C_NUM_ERASURES_P1 = 4,    /* *NumErasuresP1       (BPW:846-847; 0 for full BP)            */
+    SCLDPC_C_ITERATIONS = 5,         /* flooding iterations executed (Σ over windows for SW)          */
+    SCLDPC_C_STATUS = 6,             /* 0; -1 = the reference would have aborted (BPF:1035-1039)     */
+    SCLDPC_C_CHANNEL_ERASURES = 7,   /* Σ LLRsChannel                                                 */
+    SCLDPC_NCOUNTERS = 8
+};
+
+/* Run-level accumulators of plr_computation (BPF:1503-1520), in this order. */
+enum {
+    SCLDPC_R_USERS_ERR = 0, SCLDPC_R_FRAME_ERR = 1, SCLDPC_R_FRAME_ERR_P1 = 2, SCLDPC_R_BLOCK_ERR = 3,
+    SCLDPC_R_USERS_ERR_EXP = 4, SCLDPC_R_FRAME_ERR_EXP = 5, SCLDPC_R_BLOCK_ERR_EXP = 6,
+    SCLDPC_R_FRAMES = 7,             /* f: frames consumed, incl. the one that tripped willIstop (BPF:2143-2144) */
+    SCLDPC_R_ITERATIONS = 8,         /* Σ iterations over the consumed frames (measurement aid)       */
+    SCLDPC_NRUN = 9
+};
+
+int         scldpc_abi_version(void);
+const char *scldpc_last_error(void);           /* thread-local text of the last failing call */
+int         scldpc_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ensemble + channel sampling
+ * ------------------------------------------------------------------------------------------- */
+
+/* Exact replay of the reference's sampling on identical seeds, on the host:
+ *   perm_code := identity (inizio_sim, BPF:308-311); srandom(seed) (BPF:2062);
+ *   generate_code (BPF:1656-1761); channel_doped (BPF:1547-1574).
+ * glibc's random() (TYPE_3) is restated inside the library, so results do not depend on the
+ * host libc.  Outputs are HOST buffers: vn_adj[n*dv], chan_bits[nw]. */
+int scldpc_sample_glibc_host(const scldpc_code_params *p, uint32_t seed, double eps,
+                             int32_t ndoped, const int32_t *doped_positions,
+                             int32_t *vn_adj, uint32_t *chan_bits);
+
+/* The same for a whole reference run: ONE srandom(seed), frames drawn back to back, perm_code and
+ * the RNG stream carried from frame to frame exactly as main_terminated does (BPF:2117-2131).
+ * nframes consecutive frames are written: vn_adj[nframes][n*dv], chan_bits[nframes][nw].
+ * `state` is an opaque caller-owned blob of scldpc_glibc_state_bytes(p) bytes; initialise it with
+ * scldpc_glibc_state_init (= srandom + inizio_sim), then call _next any number of times. */
+int64_t scldpc_glibc_state_bytes(const scldpc_code_params *p);
+int     scldpc_glibc_state_init(const scldpc_code_params *p, uint32_t seed, void *state);
+int     scldpc_glibc_state_reset_perm(const scldpc_code_params *p, void *state);   /* inizio_sim only */
+int     scldpc_sample_glibc_next_host(const scldpc_code_params *p, void *state, double eps,
+                                      int32_t ndoped, const int32_t *doped_positions, int32_t nframes,
+                                      int32_t *vn_adj, uint32_t *chan_bits);
+
+/* Throughput mode: sample ntrials codes + channels ON THE DEVICE with a counter-based generator
+ * (Philox4x32-10 keyed by (seed, trial index)), same ensemble law as generate_code/channel_doped:
+ * one uniform permutation of the cns_pos*dc sockets per CN position, i.i.d. Bernoulli(eps) erasures,
+ * doped positions forced known.  Trial t of the call uses global index trial0+t, so any sharding of
+ * a run over calls / GPUs gives identical codes.  d_vn_adj [ntrials][n][dv], d_chan_bits [ntrials][nw]. */
+int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
+                                int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoders (device)
+ * ------------------------------------------------------------------------------------------- */
+
+/* decodeBP — flooding BP over the BEC to the fixpoint or max_it iterations, plus the size-2
+ * stopping-set expurgation (BPF:900-1140).  max_it <= 0 ⇒ unlimited (BPT:825 `while(1)`).
+ * is_term = 0 ⇒ truncated chain: CNs at positions >= L never send information (BPT:922-925,944-948).
+ * d_rows / d_erased_bits may be NULL.  One workgroup decodes one trial. */
+int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                          const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                          int32_t max_it, int32_t is_term,
+                          int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                          uint32_t *d_erased_bits, void *stream);
+
+/* decodeBP_SW, square window (BPW:628-912): window of W positions, init_it iterations for the
+ * first window and max_it for the others (init_it == 0 ⇒ max_it, BPW:2101-2102). */
+int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                        const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                        int32_t W, int32_t max_it, int32_t init_it,
+                        int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+
+/* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
+ * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),
+ * where k is the first trial at which frame_err reaches stop_frame_err (all trials if it never does
+ * or stop_frame_err <= 0).  A run already stopped (d_run[FRAME_ERR] >= stop_frame_err) consumes nothing. */
+int scldpc_accumulate_run_device(int32_t ntrials, const int32_t *d_counters, int64_t stop_frame_err,
+                                 int64_t *d_run, void *stream);
+
+/* LDS bytes the full-BP kernel needs for this ensemble (<= 163840 to be launchable), or a negative error. */
+int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
