@@ -19,15 +19,13 @@
 // an erased VN a belongs to such a pair iff every one of its CNs has cnt == 2 and the same partner
 // idsum - a, located in a's position.
 #include "common.h"
+#include "kernel_util.h"
 
 namespace {
 
-constexpr int kBlock = 1024;                 // 16 waves: one workgroup owns a CU's LDS
-constexpr uint32_t kCntShift = 28, kDegShift = 24;
-constexpr uint32_t kCntOne = 1u << kCntShift, kDegOne = 1u << kDegShift;
-constexpr uint32_t kSumMask = (1u << kDegShift) - 1, kDegMask = 0xFu;
-constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+using namespace scldpc_dev;
 
+constexpr int kBlock = 1024;                 // 16 waves: one workgroup owns a CU's LDS
 // scalar slots in LDS (double-buffered by iteration parity where noted)
 enum { S_VALID0 = 0, S_VALID1, S_REMOVED0, S_REMOVED1, S_PUSH0, S_PUSH1, S_OVF0, S_OVF1,
        S_NE, S_EXTRA0, S_FIRST, S_NSCAL = 16 };
@@ -46,24 +44,6 @@ struct Args {
     int32_t *rows;
     uint32_t *erased_out;
 };
-
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <int DV>
-__device__ __forceinline__ void load_adj(const int32_t *adj, int dv, int j, int32_t (&c)[8])
-{
-    if constexpr (DV == 4) {
-        const int4 v = reinterpret_cast<const int4 *>(adj)[j];
-        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-    } else {
-        for (int i = 0; i < dv; i++) c[i] = adj[(size_t)j * dv + i];
-    }
-}
 
 template <bool TRAJ, int DV>
 __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)

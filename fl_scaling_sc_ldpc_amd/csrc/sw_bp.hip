@@ -1,0 +1,269 @@
+// Square sliding-window BP over the BEC for a batch of sampled SC-LDPC codes — gfx950 kernel.
+//
+// Replaces decodeBP_SW of the reference (BPW:628-912): for posW = 0..L-1 the CNs and the VNs of
+// positions [posW, posW+W) are updated by flooding until the window's erasure count reaches 0,
+// stops changing, or the iteration cap (init_it for posW == 0, max_it afterwards; BPW:699-702,839)
+// is hit; messages persist from window to window; position posW is decided when its window ends;
+// afterwards the size-2 stopping-set expurgation over all positions (BPW:850-908).
+//
+// Same node-level restatement as full_bp.hip: S = set of VNs the CNs still see as
+// erased (1 bit per VN), one [cnt | idsum] word per CN kept exact for EVERY CN while S shrinks.
+// Inside window posW only CNs of Cw = [posW, posW+W) can fire — CNs further right were never updated
+// and send erasures, CNs further left touch no window VN — and only VNs at positions >= posW may be
+// released (older positions are frozen).  One flooding iteration == one frontier round:
+//     every CN of Cw with cnt == 1 at the start of the round releases its VN (if not frozen).
+// The frontier is found by a scan of Cw when a window opens and kept in an LDS queue afterwards.
+#include "common.h"
+#include "kernel_util.h"
+
+namespace {
+
+using namespace scldpc_dev;
+
+constexpr int kBlock = 1024;
+
+enum { S_CNT = 0, S_OVF = 3, S_NCH = 6, S_NSCAL = 16 };
+
+struct Layout {             // offsets in 32-bit words into dynamic LDS
+    int cn_state, S, fbits, q0, q1, pos_cnt, pos_ss, scal, total;
+    int qcap, nw;
+};
+
+struct Args {
+    int dv, L, vns_pos, cns_pos, n, nk, W, max_it, init_it;
+    Layout lay;
+    const int32_t *vn_adj;
+    const uint32_t *chan;
+    int32_t *counters;
+    uint32_t *erased_out;
+};
+
+template <int DV>
+__global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *cn_state = lds + a.lay.cn_state;
+    uint32_t *S = lds + a.lay.S;
+    uint32_t *fbits = lds + a.lay.fbits;
+    uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
+    int *pos_cnt = reinterpret_cast<int *>(lds + a.lay.pos_cnt);
+    int *pos_ss = reinterpret_cast<int *>(lds + a.lay.pos_ss);
+    int *scal = reinterpret_cast<int *>(lds + a.lay.scal);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int trial = blockIdx.x;
+    const int n = a.n, nk = a.nk, dv = (DV ? DV : a.dv), nw = a.lay.nw, qcap = a.lay.qcap;
+    const int V = a.vns_pos, C = a.cns_pos, L = a.L, W = a.W;
+    const int32_t *adj = a.vn_adj + (size_t)trial * n * dv;
+    const uint32_t *ch = a.chan + (size_t)trial * nw;
+
+    for (int c = tid; c < nk; c += kBlock) cn_state[c] = 0;
+    for (int w = tid; w < nw; w += kBlock) {
+        uint32_t x = ch[w];
+        if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+        S[w] = x;
+    }
+    if (tid < S_NSCAL) scal[tid] = 0;
+    for (int i = tid; i < L; i += kBlock) { pos_cnt[i] = 0; pos_ss[i] = 0; }
+    __syncthreads();
+
+    // ---- build the CN words and the per-position erasure counts from the channel ------------
+    int nch = 0;
+    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+        int32_t c[4][8];
+        bool er[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * kBlock;
+            er[u] = false;
+            if (j < n) {
+                load_adj<DV>(adj, dv, j, c[u]);
+                er[u] = (S[j >> 5] >> (j & 31)) & 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * kBlock;
+            if (j < n && er[u]) {
+                nch++;
+                atomicAdd(&pos_cnt[j / V], 1);
+                for (int i = 0; i < dv; i++) atomicAdd(&cn_state[c[u][i]], kCntOne + (uint32_t)j);
+            }
+        }
+    }
+    nch = wave_sum(nch);
+    if (lane == 0 && nch) atomicAdd(&scal[S_NCH], nch);
+    __syncthreads();
+
+    int iters_total = 0;
+    int gen = 0;                        // flooding-iteration counter: list gen lives in q[gen&1], its size in scal[S_CNT+gen%3]
+    for (int posW = 0; posW < L; posW++) {
+        const int c0 = posW * C, c1 = min(c0 + W * C, nk);                  // BPW:674-676
+        const int jlo = posW * V;                                           // BPW:691 (VNs left of it are frozen)
+        const int qhi = min(posW + W, L);                                   // BPW:692-693
+        const int cap = (posW == 0) ? a.init_it : a.max_it;                 // BPW:699-702
+        int iter = 0, prec = n, ncur = 0;
+        bool scan = true;               // a window opens with a scan of its CNs (the carried list is dropped)
+        for (;;) {
+            uint32_t *qc = q[gen & 1], *qn = q[(gen + 1) & 1];
+            int *push_cnt = &scal[S_CNT + (gen + 1) % 3], *push_ovf = &scal[S_OVF + (gen + 1) % 3];
+            auto release = [&](uint32_t c) {
+                const uint32_t w = cn_state[c];
+                if ((w >> kCntShift) != 1u) return;                         // its VN went via another CN this round
+                const uint32_t j = w & kSumMask;
+                if ((int)j < jlo) return;                                   // frozen VN: stays erased for good
+                const uint32_t bit = 1u << (j & 31);
+                const uint32_t old = atomicAnd(&S[j >> 5], ~bit);
+                if (!(old & bit)) return;
+                atomicSub(&pos_cnt[j / V], 1);
+                int32_t cc[8];
+                load_adj<DV>(adj, dv, (int)j, cc);
+                for (int i = 0; i < dv; i++) {
+                    const uint32_t c2 = (uint32_t)cc[i];
+                    const uint32_t o = atomicSub(&cn_state[c2], kCntOne + j);
+                    // 2 → 1 inside the window: fires in the next iteration.  CNs right of the window
+                    // are found by the scan of the first window that contains them.
+                    if ((o >> kCntShift) == 2u && (int)c2 < c1) {
+                        const int idx = atomicAdd(push_cnt, 1);
+                        if (idx < qcap) qn[idx] = c2; else *push_ovf = 1;
+                    }
+                }
+            };
+            if (tid == 0) { scal[S_CNT + (gen + 2) % 3] = 0; scal[S_OVF + (gen + 2) % 3] = 0; }
+            if (scan) {
+                // snapshot {c in Cw : cnt == 1} into fbits first: releases of this round must not
+                // promote CNs into the round's own frontier
+                for (int base = c0 & ~63; base < c1; base += kBlock) {
+                    const int c = base + tid;
+                    const bool v = c >= c0 && c < c1 && (cn_state[c] >> kCntShift) == 1u;
+                    const unsigned long long m = __ballot(v);
+                    if (c - lane < c1) {
+                        if (lane == 0) fbits[c >> 5] = (uint32_t)m;
+                        if (lane == 32) fbits[c >> 5] = (uint32_t)(m >> 32);
+                    }
+                }
+                __syncthreads();
+                for (int base = c0 & ~63; base < c1; base += kBlock) {
+                    const int c = base + tid;
+                    if (c < c1 && ((fbits[c >> 5] >> (c & 31)) & 1u)) release((uint32_t)c);
+                }
+            } else {
+                for (int k = tid; k < ncur; k += kBlock) release(qc[k]);
+            }
+            __syncthreads();                                                // end of the flooding iteration
+            iters_total++;
+            int term = 0;
+            for (int qq = posW; qq < qhi; qq++) term += pos_cnt[qq];        // BPW:791-809
+            scan = *push_ovf != 0;      // queue overflow: rebuild the frontier by a scan
+            ncur = min(*push_cnt, qcap);
+            gen++;
+            if (term == 0 || term == prec) break;                           // BPW:815-816
+            prec = term;
+            iter++;
+            if (!(iter < cap)) break;                                       // BPW:839
+        }
+    }
+    __syncthreads();
+
+    // ---- totals, expurgation over every position (BPW:841-847, 850-908) ---------------------
+    for (int w = tid; w < nw; w += kBlock) {
+        uint32_t x = S[w];
+        while (x) {
+            const int b = __ffs((int)x) - 1;
+            x &= x - 1;
+            const int va = w * 32 + b, pos = va / V;
+            int32_t cc[8];
+            load_adj<DV>(adj, dv, va, cc);
+            bool pair = true;
+            uint32_t partner = 0;
+            for (int i = 0; i < dv; i++) {
+                const uint32_t s = cn_state[cc[i]];
+                const uint32_t b2 = (s & kSumMask) - (uint32_t)va;
+                if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
+                partner = b2;
+            }
+            if (pair && (int)partner / V == pos) atomicAdd(&pos_ss[pos], 1);
+        }
+    }
+    __syncthreads();
+    if (a.erased_out)
+        for (int w = tid; w < nw; w += kBlock) a.erased_out[(size_t)trial * nw + w] = S[w];
+    if (tid == 0) {
+        int ne = 0, be = 0, ee = 0, bee = 0, p1 = 0;
+        const int ms = a.dv - 1;
+        for (int pos = 0; pos < L; pos++) {
+            const int cnt = pos_cnt[pos];
+            ne += cnt;
+            if (cnt > 0) be++;
+            if (pos >= ms && pos <= W - 2) p1 += cnt;                       // BPW:846-847
+            const int e = cnt - pos_ss[pos];
+            if (e > 0) { ee += e; bee++; }                                  // every position (BPW:903-907)
+        }
+        int32_t *o = a.counters + (size_t)trial * SCLDPC_NCOUNTERS;
+        o[SCLDPC_C_NUM_ERASURES] = ne;
+        o[SCLDPC_C_NUM_BLOCKS_ERR] = be;
+        o[SCLDPC_C_NUM_ERASURES_EXP] = ee;
+        o[SCLDPC_C_NUM_BLOCKS_ERR_EXP] = bee;
+        o[SCLDPC_C_NUM_ERASURES_P1] = p1;
+        o[SCLDPC_C_ITERATIONS] = iters_total;
+        o[SCLDPC_C_STATUS] = 0;
+        o[SCLDPC_C_CHANNEL_ERASURES] = scal[S_NCH];
+    }
+}
+
+int make_layout(const scldpc_code_params *p, int W, Layout *lay)
+{
+    const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
+    int off = 0;
+    auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
+    lay->nw = (n + 31) / 32;
+    lay->cn_state = take(nk);
+    lay->S = take(lay->nw);
+    lay->fbits = take(((nk + 63) / 64) * 2);
+    lay->pos_cnt = take(p->L);
+    lay->pos_ss = take(p->L);
+    lay->scal = take(S_NSCAL);
+    const int left = scldpc::kMaxLdsBytes / 4 - off;
+    int qcap = (left / 2) & ~3;
+    if (qcap > 8192) qcap = 8192;
+    if (qcap < 64) return -1;
+    (void)W;
+    lay->qcap = qcap;
+    lay->q0 = take(qcap);
+    lay->q1 = take(qcap);
+    lay->total = off;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                                   const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                   int32_t W, int32_t max_it, int32_t init_it,
+                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (ntrials < 0 || !d_counters || (ntrials > 0 && (!d_vn_adj || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: null buffer or negative ntrials");
+    if (W < 1 || max_it < 0 || init_it < 0)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: need W >= 1, max_it >= 0, init_it >= 0");
+    if (ntrials == 0) return SCLDPC_OK;
+    const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
+    if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
+    Args a{};
+    if (make_layout(p, W, &a.lay))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                 "scldpc_sw_bp_device: nk=%d CN words + n=%d VN bits do not fit 160 KiB of LDS", nk, n);
+    a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
+    a.W = W; a.max_it = max_it; a.init_it = init_it ? init_it : max_it;     // BPW:2101-2102
+    a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
+
+    void (*kern)(const Args) = p->dv == 4 ? sw_bp_kernel<4> : sw_bp_kernel<0>;
+    const size_t lds_bytes = 4u * (size_t)a.lay.total;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}

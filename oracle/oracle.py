@@ -74,6 +74,9 @@ def lib():
         L.orc_trial.argtypes = [P(Params), C.c_uint, C.c_double, C.c_int, P(C.c_int), C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, P(Result), P(C.c_uint64), i32p, i32p, u8p, u8p,
                                 C.c_void_p, C.c_int]
+        L.orc_philox4x32_10.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+        L.orc_sample_philox.argtypes = [P(Params), C.c_uint64, C.c_uint64, C.c_double, C.c_int, P(C.c_int),
+                                        i32p, P(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -124,6 +127,24 @@ def sample_trial_inputs(params, seed, eps, doped=()):
     d = (C.c_int * max(1, len(doped)))(*doped)
     L.orc_channel(C.byref(params), C.byref(g), eps, len(doped), d, _p(chan, C.c_uint8))
     return Graph(params, vn_adj, cn_ptr, cn_adj), chan
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def sample_philox(params, seed, trial, eps, doped=()):
+    """CPU twin of scldpc_sample_philox_device for one trial: (vn_adj int32 [n,dv], chan_bits uint32 [nw])."""
+    vn_adj = np.empty((params.n, params.dv), dtype=np.int32)
+    chan = np.empty((params.n + 31) // 32, dtype=np.uint32)
+    d = (C.c_int * max(1, len(doped)))(*doped)
+    lib().orc_sample_philox(C.byref(params), seed, trial, eps, len(doped), d, _p(vn_adj, C.c_int32),
+                            _p(chan, C.c_uint32))
+    return vn_adj, chan
 
 
 ROW_DTYPE = np.dtype([("deg1", np.int32), ("recovered", np.int32), ("first_pos", np.int32)])

@@ -460,3 +460,69 @@ void orc_trial(const orc_params *p, unsigned seed, double eps, int ndoped, const
     if (erased_out) memcpy(erased_out, erased, (size_t)n);
     free(perm); free(vn_adj); free(cn_ptr); free(cn_adj); free(chan); free(erased);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* CPU twin of the device's throughput-mode sampler (fl_scaling_sc_ldpc_amd/csrc/sampler.hip). */
+/* Not a restatement of reference code: the reference draws from one sequential glibc stream;  */
+/* this is the same ensemble law (BPF:1656-1761, 1547-1574) keyed by Philox4x32-10             */
+/* (Salmon, Moraes, Dror, Shaw, SC'11; published KAT vectors are checked in the tests).        */
+/* ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct { uint32_t key; int32_t sock; } keyed;
+static int keyed_cmp(const void *a, const void *b)
+{
+    const keyed *x = (const keyed *)a, *y = (const keyed *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->sock < y->sock ? -1 : (x->sock > y->sock);
+}
+
+void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, double eps,
+                       int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits)
+{
+    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, D = p->L + dv - 1, n = orc_n(p);
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int32_t *cn_local = (int32_t *)malloc(sizeof(int32_t) * (size_t)D * S);
+    keyed *ks = (keyed *)malloc(sizeof(keyed) * (size_t)S);
+    for (int pos = 0; pos < D; pos++) {
+        for (int q = 0; q < (S + 3) / 4; q++) {
+            uint32_t ctr[4] = {(uint32_t)q, (uint32_t)pos, (uint32_t)trial, (uint32_t)(trial >> 32)}, r[4];
+            orc_philox4x32_10(ctr, key, r);
+            for (int u = 0; u < 4 && q * 4 + u < S; u++) { ks[q * 4 + u].key = r[u]; ks[q * 4 + u].sock = q * 4 + u; }
+        }
+        qsort(ks, (size_t)S, sizeof(keyed), keyed_cmp);
+        for (int rank = 0; rank < S; rank++) cn_local[(size_t)pos * S + ks[rank].sock] = rank / dc;
+    }
+    for (int j = 0; j < n; j++) {
+        int pos = j / p->vns_pos, t = j % p->vns_pos;
+        for (int i = 0; i < dv; i++)
+            vn_adj[(size_t)j * dv + i] = (pos + i) * p->cns_pos + cn_local[(size_t)(pos + i) * S + dv * t + i];
+    }
+    /* erased iff r/RAND_MAX < eps, r = 31-bit draw (BPF:370,1554-1562) ⇔ r < ceil(eps*RAND_MAX) */
+    double x = eps * 2147483647.0, c = (double)(uint64_t)x;
+    if (c < x) c += 1.0;
+    const uint32_t thresh = (uint32_t)c;
+    const int nw = (n + 31) / 32;
+    memset(chan_bits, 0, sizeof(uint32_t) * (size_t)nw);
+    for (int q = 0; q < (n + 3) / 4; q++) {
+        uint32_t ctr[4] = {(uint32_t)q, 0x80000000u, (uint32_t)trial, (uint32_t)(trial >> 32)}, r[4];
+        orc_philox4x32_10(ctr, key, r);
+        for (int u = 0; u < 4 && q * 4 + u < n; u++)
+            if ((r[u] >> 1) < thresh) chan_bits[(q * 4 + u) >> 5] |= 1u << ((q * 4 + u) & 31);
+    }
+    for (int d = 0; d < ndoped; d++)
+        for (int j = doped[d] * p->vns_pos; j < (doped[d] + 1) * p->vns_pos; j++)
+            chan_bits[j >> 5] &= ~(1u << (j & 31));
+    free(cn_local); free(ks);
+}
