@@ -1,0 +1,341 @@
+"""Host-side mirror of the reference's three BP executables (simulators_sc_ldpc/bp_decoding):
+
+    bp_lim_iter INDEX W NUM_DOPED MAX_IT              (BPF main_terminated, BPF:2057-2161)
+    sw_lim_iter INDEX W NUM_DOPED MAX_IT INIT_IT      (BPW:2099-2158)
+    bp_traj     INDEX W NUM_DOPED MAX_IT IS_TERM      (BPT:2095-2178)
+
+Same positional argv, same ε grid / stop rule / output files (names and row formats of `risultati`,
+BPF:458-519, and of the trajectory dump, BPT:988,1051,1145), but the ensemble size and grid — compile
+time #defines in the reference (BPF:22-67) — are options with the reference's values as defaults, the
+frames of an ε point are decoded in device batches, and the batches of a point are sharded over the
+ranks of a torch.distributed job (one process per GPU; the only exchange is an all-gather of the
+per-trial counter rows, 32 B per trial, so that the ordered stop rule `frame_err >= 1000` cuts at the
+same frame on every rank).
+
+Two sampling modes:
+  * rng="philox" (default): codes and channels drawn on the device, counter-based, trial t of point s
+    keyed by (seed, s·2^40 + t) — any batch size / GPU count gives the same files.
+  * rng="glibc": the reference's own stream, srandom(seed) once and frames drawn back to back with
+    perm_code carried over — reproduces a reference run bit for bit on an identical seed (the
+    reference seeds from gettimeofday, BPF:2059-2062; pass --seed to pin it).  Sampling is then a
+    sequential host loop (as in the reference); decoding still runs on the device.  Single rank only.
+
+All compute is in libscldpc_hip.so; this file is orchestration and file formats.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import engine as E
+from .engine import CodeParams, NCOUNTERS, NRUN, RUN_NAMES  # noqa: F401
+
+POINT_STRIDE = 1 << 40          # philox trial index = point * POINT_STRIDE + frame
+
+
+class GridSpec:
+    """ε grid and stop rule: Def_epsIni − sim·Def_epsDelta for sim < Def_NUM_POINTS (BPF:55-61,301);
+    stop at frame_err >= min_frame_err or after max_frames frames (BPF:63-65, 440-451, 2117)."""
+
+    def __init__(self, eps_ini, eps_delta, num_points, min_frame_err, max_frames):
+        self.eps_ini, self.eps_delta, self.num_points = eps_ini, eps_delta, num_points
+        self.min_frame_err, self.max_frames = min_frame_err, max_frames
+
+    def eps(self, sim):
+        return float(self.eps_ini) - sim * float(self.eps_delta)
+
+
+# the shipped #defines of the three sources
+DEFAULTS = {
+    "bp_lim_iter": dict(N=1000, L=50, grid=GridSpec(0.48, 0.00125, 26, 1000, 1000)),
+    "sw_lim_iter": dict(N=1000, L=50, grid=GridSpec(0.475, 0.00125, 18, 1000, 1000)),
+    "bp_traj": dict(N=5000, L=50, grid=GridSpec(0.46, 0.005, 1, 500, 500)),
+}
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+class PointResult:
+    """Counters of one ε point after the stop rule, as `risultati` needs them (BPF:499-515)."""
+
+    def __init__(self, eps, n, L, run):
+        self.eps, self.n, self.L = eps, n, L
+        self.run = {k: int(v) for k, v in zip(RUN_NAMES, run)}
+        self.f = self.run["frames"]
+
+    def row(self):
+        r, f, n, L = self.run, self.f, self.n, self.L
+        vals = (self.eps, r["users_err"] / n / f, r["frame_err"] / f, r["block_err"] / L / f,
+                r["users_err_exp"] / n / f, r["frame_err_exp"] / f, r["block_err_exp"] / L / f)
+        ints = (n, L, f, r["users_err"], r["frame_err"], r["block_err"], r["users_err_exp"],
+                r["frame_err_exp"], r["block_err_exp"])
+        return "%f %e %e %e %e %e %e " % vals + " ".join("%d" % v for v in ints) + "\n"
+
+
+RISULTATI_HEADER = ("p BER FER BLER BER_EXP FER_EXP BLER_EXP n L f users_err frame_err block_err "
+                    "users_err_exp frame_err_exp block_err_exp\n")
+
+
+def result_filename(prog, p, W, max_it, init_it, index):
+    """BPF:487 / BPW:488.  (The reference prints Def_M = CNs per position as `M`.)"""
+    if prog == "sw_lim_iter":
+        return "SC_LDPC_%d_%d_L%d_M%d_BP_SW%d_%dit_%dinit_Random_BLER_%d.dat" % (
+            p.dv, p.dc, p.L, p.cns_pos, W, max_it, init_it, index)
+    return "SC_LDPC_%d_%d_L%d_M%d_BP_SW%d_%dit_Random_BLER_%d.dat" % (p.dv, p.dc, p.L, p.cns_pos, W, max_it, index)
+
+
+def traj_filename(p, eps, max_it, is_term, index):
+    """BPT:2131-2134."""
+    kind = "terminated" if is_term else "truncated"
+    return "trajectories_%.4f_%s_SC_LDPC_%d_%d_L%d_M%d_BP_Full_%dit_Random_BLER_%d.dat" % (
+        eps, kind, p.dv, p.dc, p.L, p.cns_pos, max_it, index)
+
+
+def write_risultati(path, sim, point):
+    """First point truncates and writes the header, later points append (BPF:489-497)."""
+    with open(path, "w" if sim == 0 else "a") as f:
+        if sim == 0:
+            f.write(RISULTATI_HEADER)
+        f.write(point.row())
+
+
+class Simulator:
+    """Batched Monte-Carlo driver around the device decoders."""
+
+    def __init__(self, p, decoder="full", W=0, max_it=0, init_it=0, is_term=True, doped=(), batch=2048,
+                 rng="philox", seed=1, device=None, rows_cap=0):
+        self.p, self.decoder, self.W, self.max_it, self.init_it = p, decoder, W, max_it, init_it
+        self.is_term, self.doped, self.batch, self.rng, self.seed = is_term, tuple(doped), batch, rng, seed
+        self.rows_cap = rows_cap
+        self.dist, self.rank, self.world = _dist()
+        self.device = torch.device(device if device is not None else
+                                   "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        if rng == "glibc":
+            if self.world != 1:
+                raise ValueError("rng='glibc' replays one sequential reference stream: single rank only")
+            self.glibc = E.GlibcRun(p, seed)
+        elif rng != "philox":
+            raise ValueError("rng must be 'philox' or 'glibc'")
+        self._alloc()
+
+    def _alloc(self):
+        p, batch = self.p, self.batch
+        self.d_adj = torch.empty((batch, p.n, p.dv), dtype=torch.int32, device=self.device)
+        self.d_ch = torch.empty((batch, p.nw), dtype=torch.int32, device=self.device)
+        self.d_cnt = torch.empty((batch, NCOUNTERS), dtype=torch.int32, device=self.device)
+
+    def _accumulate(self, allcnt, run, stop_frame_err):
+        return E.accumulate_run(allcnt, run, stop_frame_err)
+
+    def _new_run(self):
+        return E.new_run(self.device)
+
+    # -- one device batch ------------------------------------------------------------------------
+    def decode_batch(self, nb, want_rows=False):
+        adj, ch, cnt = self.d_adj[:nb], self.d_ch[:nb], self.d_cnt[:nb]
+        if self.decoder == "sw":
+            return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt)
+        return E.full_bp(self.p, adj, ch, max_it=self.max_it, is_term=self.is_term,
+                         rows_cap=self.rows_cap if want_rows else 0, counters=cnt)
+
+    def fill_batch(self, sim, eps, frame0, nb):
+        if self.rng == "philox":
+            E.sample_philox(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+                            out=(self.d_adj[:nb], self.d_ch[:nb]))
+        else:
+            adj, ch = self.glibc.next_frames(nb, eps, self.doped)
+            self.d_adj[:nb].copy_(torch.from_numpy(adj))
+            self.d_ch[:nb].copy_(torch.from_numpy(ch.view(np.int32)))
+
+    # -- one ε point -------------------------------------------------------------------------------
+    def run_point(self, sim, eps, min_frame_err, max_frames, on_batch=None):
+        """Frames 0,1,2,… of the point until frame_err >= min_frame_err or max_frames frames, in frame
+        order (BPF:2117-2144).  In every round rank r decodes the r-th of `world` consecutive batches;
+        the per-trial counter rows are all-gathered and accumulated in frame order on every rank, so all
+        ranks cut at the same frame.  on_batch(frame0, frames_used, result) sees this rank's batches."""
+        p, B, W = self.p, self.batch, self.world
+        i_frames, i_ferr, i_status = RUN_NAMES.index("frames"), RUN_NAMES.index("frame_err"), \
+            E.COUNTER_NAMES.index("status")
+        if self.rng == "glibc":
+            self.glibc.new_point()
+        run = self._new_run()
+        frame0, consumed = 0, 0
+        while frame0 < max_frames:
+            sizes = [max(0, min(B, max_frames - (frame0 + r * B))) for r in range(W)]
+            nb = sizes[self.rank]
+            res = None
+            snap = self.glibc.snapshot() if self.rng == "glibc" else None
+            if nb:
+                self.fill_batch(sim, eps, frame0 + self.rank * B, nb)
+                res = self.decode_batch(nb, want_rows=on_batch is not None and self.rows_cap > 0)
+            if W > 1:
+                if nb < B:
+                    self.d_cnt[nb:].zero_()
+                gathered = [torch.empty_like(self.d_cnt) for _ in range(W)]
+                self.dist.all_gather(gathered, self.d_cnt)
+                allcnt = torch.cat([g[:s] for g, s in zip(gathered, sizes)], dim=0).contiguous()
+            else:
+                allcnt = self.d_cnt[:nb]
+            self._accumulate(allcnt, run, min_frame_err)
+            r = run.cpu().numpy()
+            used_round = int(r[i_frames]) - consumed
+            consumed = int(r[i_frames])
+            if bool((allcnt[:used_round, i_status] != 0).any()):
+                # the reference aborts the process here (BPF:1035-1039)
+                print("ARGH! RECOVERED MORE VNs THAN deg-1 CNs! Aborting!")
+                raise SystemExit(-1)
+            if on_batch is not None and nb:
+                on_batch(frame0 + self.rank * B, max(0, min(nb, used_round - sum(sizes[:self.rank]))), res)
+            stopped = min_frame_err > 0 and r[i_ferr] >= min_frame_err
+            if stopped and snap is not None and used_round < nb:
+                # the reference stops drawing at the tripping frame: rewind the stream to just after it
+                self.glibc.restore(snap)
+                self.glibc.next_frames(used_round, eps, self.doped)
+            frame0 += sum(sizes)
+            if stopped:
+                break
+        return PointResult(eps, p.n, p.L, run.cpu().numpy())
+
+
+def _write_traj_rows(fh, rows, counters, nb):
+    """Per frame: one line per iteration `iter\\tdeg1\\trecovered\\tfirst_pos`, then an empty line
+    (BPT:988,1051,1145)."""
+    rows = rows.cpu().numpy()
+    its = counters[:, E.COUNTER_NAMES.index("iterations")].cpu().numpy()
+    out = []
+    for t in range(nb):
+        k = int(its[t])
+        if k > rows.shape[1]:
+            raise RuntimeError(f"trajectory of {k} iterations exceeds rows_cap={rows.shape[1]}; raise --rows-cap")
+        r = rows[t, :k]
+        out.append("".join("%d\t%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1], r[i, 2]) for i in range(k)))
+        out.append("\n")
+    fh.write("".join(out))
+
+
+def run_program(prog, index, W, num_doped, max_it, extra, opts):
+    """The body of main_terminated for one of the three executables."""
+    d = DEFAULTS[prog]
+    N = opts.N if opts.N else d["N"]
+    L = opts.L if opts.L else d["L"]
+    g = d["grid"]
+    grid = GridSpec(opts.eps_ini if opts.eps_ini is not None else g.eps_ini,
+                    opts.eps_delta if opts.eps_delta is not None else g.eps_delta,
+                    opts.num_points if opts.num_points else g.num_points,
+                    opts.min_frame_err if opts.min_frame_err is not None else g.min_frame_err,
+                    opts.max_frames if opts.max_frames else g.max_frames)
+    p = E.make_params(opts.dv, opts.dc, L, N)
+    # argv quirk kept: main_terminated reads the doped positions starting at argv[4], which is also
+    # MAX_IT (BPF:2083-2091) — so with NUM_DOPED > 0 the first doped position equals MAX_IT.
+    tail = [max_it] + list(opts.doped_argv)
+    doped = [int(x) for x in tail[:num_doped]]
+    if len(doped) < num_doped:
+        raise SystemExit("NUM_DOPED=%d but only %d position arguments" % (num_doped, len(doped)))
+    init_it, is_term = 0, True
+    decoder = "full"
+    if prog == "sw_lim_iter":
+        decoder = "sw"
+        init_it = extra if extra else max_it                       # BPW:2101-2102
+    elif prog == "bp_traj":
+        is_term = bool(extra)
+    dist, rank, world = _dist()
+    sim_obj = Simulator(p, decoder=decoder, W=W, max_it=(0 if prog == "bp_traj" else max_it), init_it=init_it,
+                        is_term=is_term, doped=doped, batch=opts.batch, rng=opts.rng, seed=opts.seed,
+                        rows_cap=opts.rows_cap if prog == "bp_traj" else 0)
+    outdir = opts.outdir
+    os.makedirs(outdir, exist_ok=True)
+    t0 = time.time()
+    for sim in range(grid.num_points):
+        eps = grid.eps(sim)
+        if prog == "bp_traj":
+            # one file per point and per rank-local batch order; bp_traj is a 1-point, ≤500-frame program
+            # (BPT:61-65): run it on one rank so the file keeps frame order.
+            if world != 1:
+                raise SystemExit("bp_traj writes frames in order: run it on a single rank")
+            path = os.path.join(outdir, traj_filename(p, eps, max_it, is_term, index))
+            with open(path, "w") as fh:
+                def on_batch(frame0, used, res):
+                    _write_traj_rows(fh, res["rows"], res["counters"], used)
+                point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames, on_batch=on_batch)
+        else:
+            point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames)
+            if rank == 0:
+                write_risultati(os.path.join(outdir, result_filename(prog, p, W, max_it, init_it, index)), sim, point)
+        if rank == 0 and not opts.quiet:
+            r = point.run
+            print("%f %e %e %e   (f=%d, %.1fs)" % (eps, r["users_err"] / p.n / point.f, r["frame_err"] / point.f,
+                                                   r["block_err"] / p.L / point.f, point.f, time.time() - t0),
+                  flush=True)
+    return 0
+
+
+def _parser(prog):
+    ap = argparse.ArgumentParser(prog=prog, description=__doc__.split("\n\n")[0])
+    ap.add_argument("INDEX", type=int)
+    ap.add_argument("W", type=int)
+    ap.add_argument("NUM_DOPED", type=int)
+    ap.add_argument("MAX_IT", type=int)
+    if prog == "sw_lim_iter":
+        ap.add_argument("INIT_IT", type=int)
+    elif prog == "bp_traj":
+        ap.add_argument("IS_TERM", type=int)
+    ap.add_argument("doped_argv", nargs="*", type=int, help="further doped positions (see the argv quirk)")
+    ap.add_argument("--dv", type=int, default=4)
+    ap.add_argument("--dc", type=int, default=8)
+    ap.add_argument("--L", type=int, default=0, help="Def_L (default: the source's value)")
+    ap.add_argument("--N", type=int, default=0, help="VNs per position = Def_VNsPos = 2*Def_M")
+    ap.add_argument("--eps-ini", type=float, default=None)
+    ap.add_argument("--eps-delta", type=float, default=None)
+    ap.add_argument("--num-points", type=int, default=0)
+    ap.add_argument("--min-frame-err", type=int, default=None)
+    ap.add_argument("--max-frames", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=2048, help="frames per device batch and rank")
+    ap.add_argument("--rng", choices=("philox", "glibc"), default="philox")
+    ap.add_argument("--seed", type=int, default=None, help="default: time-based like the reference (BPF:2059-2062)")
+    ap.add_argument("--rows-cap", type=int, default=4096, help="bp_traj: max iterations kept per frame")
+    ap.add_argument("--outdir", default=".")
+    ap.add_argument("--quiet", action="store_true")
+    return ap
+
+
+def main(prog, argv=None):
+    opts = _parser(prog).parse_args(argv)
+    if opts.seed is None:
+        opts.seed = int((time.time() % 1) * 1e6)                      # te.tv_usec (BPF:2061)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    extra = getattr(opts, "INIT_IT", None) if prog == "sw_lim_iter" else getattr(opts, "IS_TERM", None)
+    rc = run_program(prog, opts.INDEX, opts.W, opts.NUM_DOPED, opts.MAX_IT, extra, opts)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return rc
+
+
+def bp_lim_iter(argv=None):
+    return main("bp_lim_iter", argv)
+
+
+def sw_lim_iter(argv=None):
+    return main("sw_lim_iter", argv)
+
+
+def bp_traj(argv=None):
+    return main("bp_traj", argv)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] not in DEFAULTS:
+        raise SystemExit("usage: python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj} ARGS…")
+    sys.exit(main(sys.argv[1], sys.argv[2:]))

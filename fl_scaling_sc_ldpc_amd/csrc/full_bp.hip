@@ -4,20 +4,23 @@
 // BPT:912-1051) bit for bit, but does O(E) work per trial instead of O(E·iterations):
 // on the BEC, the a-posteriori erasure set after flooding iteration t equals the residual of
 // level-synchronous parallel peeling after t rounds, so the kernel keeps
-//   * one bit per VN  (U  = currently erased VNs), and
-//   * one 32-bit word per CN: [cnt:4 | deg:4 | idsum:24] where cnt = #erased neighbours and
-//     idsum = Σ of their VN ids — when cnt == 1 the idsum IS the id of the one erased neighbour,
-//     so only the VN→CN table is ever read from HBM (no CN→VN lists, no per-edge messages),
+//   * one bit per VN  (U = currently erased VNs), and
+//   * one small word per CN holding cnt = #erased neighbours and a fold (sum or xor) of their ids —
+//     when cnt == 1 the fold IS the one erased neighbour, so only the VN→CN table is ever read
+//     from HBM (no CN→VN lists, no per-edge messages),
 // all of it in LDS (one workgroup = one trial), and walks a frontier of CNs with cnt == 1.
 //
-// Iteration t of the reference == one pass of the loop below:
-//   phase B  count the valid frontier  → deg_1_iter        (BPF:969-978)
-//   phase A  every frontier CN releases its VN; the releasing thread fetches that VN's dv CN ids
-//            (one 16-B load), decrements those CNs and queues the ones that drop to cnt == 1
-//   then     NumErasures / stop tests / optional trajectory row (BPF:1044-1065, BPT:988,1051)
-// and afterwards the size-2 stopping-set expurgation (BPF:1067-1133) from the same CN words:
-// an erased VN a belongs to such a pair iff every one of its CNs has cnt == 2 and the same partner
-// idsum - a, located in a's position.
+// Two CN-word layouts:
+//   Wide   32 bit  [cnt:4 | deg:4 | Σ global VN id:24]   any ensemble that fits; needed for trajectories (deg)
+//   Packed 16 bit  [cnt:4 | ⊕ local VN id:12]            when dv·vns_pos <= 4096 (local id = edge·vns_pos + t):
+//                  half the LDS ⇒ two 512-thread workgroups per CU hide each other's HBM latency.
+//
+// Iteration t of the reference == one frontier round (one barrier):
+//   every CN with cnt == 1 at the start of the round releases its VN; the releasing thread fetches the
+//   VN's dv CN ids (one 16-B load), decrements those CNs and queues the ones that drop 2 → 1.
+//   deg_1_iter (BPF:969-978) needs no extra pass:  |F(t+1)| = pushes(t) − (drops_1→0(t) − |F(t)|).
+// Afterwards the size-2 stopping-set expurgation (BPF:1067-1133) from the same CN words: an erased VN a
+// belongs to such a pair iff every one of its CNs has cnt == 2 and the same partner, in a's position.
 #include "common.h"
 #include "kernel_util.h"
 
@@ -25,18 +28,17 @@ namespace {
 
 using namespace scldpc_dev;
 
-constexpr int kBlock = 1024;                 // 16 waves: one workgroup owns a CU's LDS
-// scalar slots in LDS (double-buffered by iteration parity where noted)
-enum { S_VALID0 = 0, S_VALID1, S_REMOVED0, S_REMOVED1, S_PUSH0, S_PUSH1, S_OVF0, S_OVF1,
-       S_NE, S_EXTRA0, S_FIRST, S_NSCAL = 16 };
+// per-iteration counters, rotated three ways so that one barrier per iteration is enough
+enum { S_PUSH = 0, S_DROP = 3, S_REM = 6, S_OVF = 9, S_NE = 12, S_EXTRA0 = 13, S_VALID = 14, S_NSCAL = 16 };
 
 struct Layout {             // offsets in 32-bit words into dynamic LDS
     int cn_state, U, fbits, q0, q1, pos_cnt, pos_ss, scal, total;
-    int qcap, nw, fwords;
+    int qcap, nw;
 };
 
 struct Args {
-    int dv, L, vns_pos, n, nk, cn_lim, max_it, rows_cap;
+    int dv, L, vns_pos, cns_pos, n, nk, cn_lim, max_it, rows_cap;
+    uint32_t magic_v, magic_c;      // floor(2^32/d)+1: x/d == umulhi(x, magic) for the ranges used here
     Layout lay;
     const int32_t *vn_adj;
     const uint32_t *chan;
@@ -45,8 +47,79 @@ struct Args {
     uint32_t *erased_out;
 };
 
-template <bool TRAJ, int DV>
-__global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
+struct Vn { int j, pos, t; };
+
+// ---- CN-word policies --------------------------------------------------------------------------
+struct Wide {
+    static __host__ __device__ int words(int nk) { return nk; }
+    static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int, int, bool erased, bool deg)
+    {
+        atomicAdd(&st[c], (deg ? kDegOne : 0u) + (erased ? kCntOne + (uint32_t)v.j : 0u));
+    }
+    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return st[c] >> kCntShift; }
+    static __device__ __forceinline__ uint32_t deg(const uint32_t *st, int c) { return (st[c] >> kDegShift) & kDegMask; }
+    // the single erased neighbour of c (valid only if cnt == 1 in the word that was read); -1 otherwise
+    static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &)
+    {
+        const uint32_t w = st[c];
+        return (w >> kCntShift) == 1u ? (int)(w & kSumMask) : -1;
+    }
+    static __device__ __forceinline__ uint32_t remove(uint32_t *st, int c, const Vn &v, int, int)   // returns old cnt
+    {
+        return atomicSub(&st[c], kCntOne + (uint32_t)v.j) >> kCntShift;
+    }
+    // partner of v at CN c if cnt == 2, else -1
+    static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int, const Args &)
+    {
+        const uint32_t w = st[c];
+        return (w >> kCntShift) == 2u ? (int)((w & kSumMask) - (uint32_t)v.j) : -1;
+    }
+};
+
+struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of word c >> 1
+    static __host__ __device__ int words(int nk) { return (nk + 1) / 2; }
+    static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int i, int V, bool erased, bool)
+    {
+        if (!erased) return;
+        const int sh = (c & 1) * 16;
+        atomicAdd(&st[c >> 1], 0x1000u << sh);
+        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << sh);
+    }
+    static __device__ __forceinline__ uint32_t half(const uint32_t *st, int c) { return (st[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu; }
+    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return half(st, c) >> 12; }
+    static __device__ __forceinline__ uint32_t deg(const uint32_t *, int) { return 0; }
+    static __device__ __forceinline__ int lid_to_vn(int c, uint32_t lid, const Args &a)
+    {
+        const int V = a.vns_pos;
+        int i = 0;
+        while ((i + 1) * V <= (int)lid) i++;                         // < dv steps
+        const int pos_c = (int)__umulhi((uint32_t)c, a.magic_c);
+        return (pos_c - i) * V + ((int)lid - i * V);
+    }
+    static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &a)
+    {
+        // cnt and fold are updated by two atomics (remove(): count first, fold second).  The only update a
+        // CN of the CURRENT frontier can see in its round is the removal of its own VN, which drops cnt to 0
+        // before it touches the fold — so a frontier CN read with cnt == 1 carries exactly its one neighbour.
+        const uint32_t h = half(st, c);
+        return (h >> 12) == 1u ? lid_to_vn(c, h & 0xFFFu, a) : -1;
+    }
+    static __device__ __forceinline__ uint32_t remove(uint32_t *st, int c, const Vn &v, int i, int V)
+    {
+        const int sh = (c & 1) * 16;
+        const uint32_t o = (atomicSub(&st[c >> 1], 0x1000u << sh) >> (sh + 12)) & 0xFu;
+        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << sh);
+        return o;
+    }
+    static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int i, const Args &a)
+    {
+        const uint32_t h = half(st, c);
+        return (h >> 12) == 2u ? lid_to_vn(c, (h & 0xFFFu) ^ (uint32_t)(i * a.vns_pos + v.t), a) : -1;
+    }
+};
+
+template <class ST, bool TRAJ, int DV, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *cn_state = lds + a.lay.cn_state;
@@ -60,32 +133,34 @@ __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int trial = blockIdx.x;
     const int n = a.n, nk = a.nk, dv = (DV ? DV : a.dv), cn_lim = a.cn_lim, nw = a.lay.nw, qcap = a.lay.qcap;
+    const int V = a.vns_pos;
     const int32_t *adj = a.vn_adj + (size_t)trial * n * dv;
     const uint32_t *ch = a.chan + (size_t)trial * nw;
+    auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
 
     // ---- load channel bits, clear CN words -------------------------------------------------
-    for (int c = tid; c < nk; c += kBlock) cn_state[c] = 0;
+    for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
     int ne_local = 0;
-    for (int w = tid; w < nw; w += kBlock) {
+    for (int w = tid; w < nw; w += BLOCK) {
         uint32_t x = ch[w];
         if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
         U[w] = x;
         ne_local += __popc(x);
     }
     if (tid < S_NSCAL) scal[tid] = 0;
-    for (int i = tid; i < a.L; i += kBlock) { pos_cnt[i] = 0; pos_ss[i] = 0; }
+    for (int i = tid; i < a.L; i += BLOCK) { pos_cnt[i] = 0; pos_ss[i] = 0; }
     __syncthreads();
     ne_local = wave_sum(ne_local);
     if (lane == 0 && ne_local) atomicAdd(&scal[S_NE], ne_local);
 
-    // ---- build: every erased VN adds (1, id) to its dv CNs (TRAJ: every VN also adds to deg) ----
+    // ---- build: every erased VN adds itself to its dv CNs (TRAJ: every VN also adds to deg) ----
     // Loads are unconditional so that each wave instruction reads 1 KiB contiguous (dv = 4).
-    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {
         int32_t c[4][8];
         bool er[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + u * kBlock;
+            const int j = j0 + u * BLOCK;
             er[u] = false;
             if (j < n) {
                 load_adj<DV>(adj, dv, j, c[u]);
@@ -94,10 +169,10 @@ __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + u * kBlock;
+            const int j = j0 + u * BLOCK;
             if (j < n && (TRAJ || er[u])) {
-                const uint32_t add = (TRAJ ? kDegOne : 0u) + (er[u] ? kCntOne + (uint32_t)j : 0u);
-                for (int i = 0; i < dv; i++) atomicAdd(&cn_state[c[u][i]], add);
+                const Vn v = make_vn(j);
+                for (int i = 0; i < dv; i++) ST::add(cn_state, c[u][i], v, i, V, er[u], TRAJ);
             }
         }
     }
@@ -105,91 +180,83 @@ __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
 
     int ne = scal[S_NE];
     const int nch = ne;
-    int prec = n, iter = 0, ncur = 0, status = 0, rows_done = 0;
+    int prec = n, iter = 0, ncur = 0, status = 0, rows_done = 0, nfront = 0;
     bool scan = true;                   // iteration 0 has no queue yet: frontier = all CNs with cnt == 1
     int first_word = 0;
 
     for (;;) {
-        const int par = iter & 1;
-        uint32_t *qc = q[par], *qn = q[par ^ 1];
+        const int g = iter % 3, gn = (iter + 1) % 3;
+        uint32_t *qc = q[iter & 1], *qn = q[(iter + 1) & 1];
+        if (tid == 0) { scal[S_PUSH + gn] = 0; scal[S_DROP + gn] = 0; scal[S_REM + gn] = 0; scal[S_OVF + gn] = 0; }
 
-        // ---- phase B: validate + count the frontier (= deg_1_iter) -------------------------
-        int valid = 0, extra = 0;
+        int removed = 0, drops = 0;
+        auto release = [&](int c) {
+            const int j = ST::lone_vn(cn_state, c, a);
+            if (j < 0) return;                                      // its VN was just released via another CN
+            const uint32_t bit = 1u << (j & 31);
+            const uint32_t old = atomicAnd(&U[j >> 5], ~bit);
+            if (!(old & bit)) return;                               // lost the race for VN j
+            removed++;
+            const Vn v = make_vn(j);
+            int32_t cc[8];
+            load_adj<DV>(adj, dv, j, cc);
+            for (int i = 0; i < dv; i++) {
+                const int c2 = cc[i];
+                const uint32_t o = ST::remove(cn_state, c2, v, i, V);
+                if (c2 < cn_lim) {
+                    drops += (o == 1u);
+                    if (o == 2u) {                                  // 2 → 1: candidate for the next round
+                        const int idx = atomicAdd(&scal[S_PUSH + g], 1);
+                        if (idx < qcap) qn[idx] = (uint32_t)c2; else scal[S_OVF + g] = 1;
+                    }
+                }
+            }
+        };
         if (scan) {
-            for (int base = 0; base < cn_lim; base += kBlock) {
+            // snapshot {c < cn_lim : cnt == 1} first: this round's releases must not promote CNs into it
+            int valid = 0, extra = 0;
+            for (int base = 0; base < cn_lim; base += BLOCK) {
                 const int c = base + tid;
                 bool v = false;
                 if (c < cn_lim) {
-                    const uint32_t w = cn_state[c];
-                    v = (w >> kCntShift) == 1u;
-                    if (TRAJ && iter == 0)          // degree-1 CN whose only VN is known (BPF:973)
-                        extra += ((w >> kCntShift) == 0u && ((w >> kDegShift) & kDegMask) == 1u);
+                    const uint32_t k = ST::cnt(cn_state, c);
+                    v = k == 1u;
+                    if (TRAJ && iter == 0)                          // degree-1 CN whose only VN is known (BPF:973)
+                        extra += (k == 0u && ST::deg(cn_state, c) == 1u);
                 }
                 const unsigned long long m = __ballot(v);
-                if (c - lane < cn_lim) {            // this wave's 64-CN slice starts inside the range
+                if (c - lane < cn_lim) {                            // this wave's 64-CN slice starts inside the range
                     if (lane == 0) fbits[c >> 5] = (uint32_t)m;
                     if (lane == 32) fbits[c >> 5] = (uint32_t)(m >> 32);
                 }
                 valid += v;
             }
-        } else {
-            for (int k = tid; k < ncur; k += kBlock) {
-                const uint32_t c = qc[k];
-                const bool v = (cn_state[c] >> kCntShift) == 1u;   // dropped to 0 within the round it was queued?
-                if (!v) qc[k] = kInvalid;
-                valid += v;
-            }
-        }
-        valid = wave_sum(valid);
-        if (lane == 0 && valid) atomicAdd(&scal[S_VALID0 + par], valid);
-        if (TRAJ && iter == 0) {
-            extra = wave_sum(extra);
-            if (lane == 0 && extra) atomicAdd(&scal[S_EXTRA0], extra);
-        }
-        __syncthreads();                                            // (1)
-        if (tid == 0) {         // counters of the NEXT iteration; last read before barrier (1)
-            scal[S_VALID0 + (par ^ 1)] = 0; scal[S_REMOVED0 + (par ^ 1)] = 0;
-            scal[S_PUSH0 + (par ^ 1)] = 0; scal[S_OVF0 + (par ^ 1)] = 0;
-        }
-        const int deg1 = scal[S_VALID0 + par] + ((TRAJ && iter == 0) ? scal[S_EXTRA0] : 0);
-
-        // ---- phase A: release the VN of every frontier CN ----------------------------------
-        int removed = 0;
-        auto release = [&](uint32_t c) {
-            const uint32_t w = cn_state[c];
-            if ((w >> kCntShift) != 1u) return;                     // its VN was just released via another CN
-            const uint32_t j = w & kSumMask, bit = 1u << (j & 31);
-            const uint32_t old = atomicAnd(&U[j >> 5], ~bit);
-            if (!(old & bit)) return;                               // lost the race for VN j
-            removed++;
-            int32_t cc[8];
-            load_adj<DV>(adj, dv, (int)j, cc);
-            for (int i = 0; i < dv; i++) {
-                const uint32_t c2 = (uint32_t)cc[i];
-                const uint32_t o = atomicSub(&cn_state[c2], kCntOne + j);
-                if ((o >> kCntShift) == 2u && (int)c2 < cn_lim) {   // 2 → 1: candidate for the next round
-                    const int idx = atomicAdd(&scal[S_PUSH0 + par], 1);
-                    if (idx < qcap) qn[idx] = c2; else scal[S_OVF0 + par] = 1;
+            if (iter == 0) {
+                valid = wave_sum(valid);
+                if (lane == 0 && valid) atomicAdd(&scal[S_VALID], valid);
+                if (TRAJ) {
+                    extra = wave_sum(extra);
+                    if (lane == 0 && extra) atomicAdd(&scal[S_EXTRA0], extra);
                 }
             }
-        };
-        if (scan) {
-            for (int base = 0; base < cn_lim; base += kBlock) {
+            __syncthreads();
+            if (iter == 0) nfront = scal[S_VALID];
+            for (int base = 0; base < cn_lim; base += BLOCK) {
                 const int c = base + tid;
-                if (c < cn_lim && ((fbits[c >> 5] >> (c & 31)) & 1u)) release((uint32_t)c);
+                if (c < cn_lim && ((fbits[c >> 5] >> (c & 31)) & 1u)) release(c);
             }
         } else {
-            for (int k = tid; k < ncur; k += kBlock) {
-                const uint32_t c = qc[k];
-                if (c != kInvalid) release(c);
-            }
+            for (int k = tid; k < ncur; k += BLOCK) release((int)qc[k]);
         }
         removed = wave_sum(removed);
-        if (lane == 0 && removed) atomicAdd(&scal[S_REMOVED0 + par], removed);
-        __syncthreads();                                            // (2)
+        drops = wave_sum(drops);
+        if (lane == 0 && removed) atomicAdd(&scal[S_REM + g], removed);
+        if (lane == 0 && drops) atomicAdd(&scal[S_DROP + g], drops);
+        __syncthreads();                                            // end of flooding iteration `iter`
 
         // ---- bookkeeping, identical in every thread ----------------------------------------
-        ne -= scal[S_REMOVED0 + par];
+        const int deg1 = nfront + ((TRAJ && iter == 0) ? scal[S_EXTRA0] : 0);
+        ne -= scal[S_REM + g];
         const int recovered = prec - ne;
         if (TRAJ && (tid >> 6) == 0 && a.rows && rows_done < a.rows_cap) {
             // first erased VN (BPT:1037-1038): U only loses bits, so resume from the last hit
@@ -209,46 +276,48 @@ __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
             first_word = fw;
             if (lane == 0) {
                 int32_t *r = a.rows + ((size_t)trial * a.rows_cap + rows_done) * 3;
-                r[0] = deg1; r[1] = recovered; r[2] = first / a.vns_pos;
+                r[0] = deg1; r[1] = recovered; r[2] = first / V;
             }
         }
+        if (TRAJ) __syncthreads();      // wave 0 read U above: keep the next round's releases behind it
         rows_done++;
         if (deg1 < recovered && iter > 0) { status = -1; break; }   // BPF:1035-1039
         if (ne == 0 || ne == prec) break;                           // BPF:1044-1045
         prec = ne;
+        // frontier of the next round: queued 2→1 CNs minus those that went on to 0 within this round
+        nfront = scal[S_PUSH + g] - (scal[S_DROP + g] - nfront);
+        scan = scal[S_OVF + g] != 0;
+        ncur = scan ? 0 : scal[S_PUSH + g];
         iter++;
-        scan = scal[S_OVF0 + par] != 0;
-        ncur = scan ? 0 : scal[S_PUSH0 + par];
         if (a.max_it > 0 && iter >= a.max_it) break;                // BPF:1065
     }
     __syncthreads();
 
     // ---- per-position erasure counts + size-2 stopping sets (BPF:1067-1133) -----------------
     if (ne > 0) {
-        for (int w = tid; w < nw; w += kBlock) {
+        for (int w = tid; w < nw; w += BLOCK) {
             uint32_t x = U[w];
             while (x) {
                 const int b = __ffs((int)x) - 1;
                 x &= x - 1;
-                const int va = w * 32 + b, pos = va / a.vns_pos;
-                atomicAdd(&pos_cnt[pos], 1);
+                const Vn v = make_vn(w * 32 + b);
+                atomicAdd(&pos_cnt[v.pos], 1);
                 int32_t cc[8];
-                load_adj<DV>(adj, dv, va, cc);
+                load_adj<DV>(adj, dv, v.j, cc);
                 bool pair = true;
-                uint32_t partner = 0;
+                int partner = -1;
                 for (int i = 0; i < dv; i++) {
-                    const uint32_t s = cn_state[cc[i]];
-                    const uint32_t b2 = (s & kSumMask) - (uint32_t)va;
-                    if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
+                    const int b2 = ST::partner(cn_state, cc[i], v, i, a);
+                    if (b2 < 0 || (i > 0 && b2 != partner)) { pair = false; break; }
                     partner = b2;
                 }
-                if (pair && (int)partner / a.vns_pos == pos) atomicAdd(&pos_ss[pos], 1);
+                if (pair && (int)__umulhi((uint32_t)partner, a.magic_v) == v.pos) atomicAdd(&pos_ss[v.pos], 1);
             }
         }
     }
     __syncthreads();
     if (a.erased_out)
-        for (int w = tid; w < nw; w += kBlock) a.erased_out[(size_t)trial * nw + w] = U[w];
+        for (int w = tid; w < nw; w += BLOCK) a.erased_out[(size_t)trial * nw + w] = U[w];
     if (tid == 0) {
         int be = 0, ee = 0, bee = 0;
         for (int pos = 0; pos < a.L; pos++) {
@@ -268,29 +337,45 @@ __global__ __launch_bounds__(kBlock) void full_bp_kernel(const Args a)
     }
 }
 
-int make_layout(const scldpc_code_params *p, Layout *lay)
+// LDS carve.  `budget` = bytes this workgroup may take (160 KiB alone on the CU, 80 KiB when two share it).
+template <class ST>
+int make_layout(const scldpc_code_params *p, int budget_bytes, Layout *lay)
 {
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };   // keep 16-B alignment
     lay->nw = (n + 31) / 32;
-    lay->fwords = ((nk + 63) / 64) * 2;
-    lay->cn_state = take(nk);
-    lay->U = take(lay->nw + 64);              // +64: the first-erased scan may peek one wave past the end
-    lay->fbits = take(lay->fwords);
+    lay->cn_state = take(ST::words(nk));
+    lay->U = take(lay->nw);
+    lay->fbits = take(((nk + 63) / 64) * 2);
     lay->pos_cnt = take(p->L);
     lay->pos_ss = take(p->L);
     lay->scal = take(S_NSCAL);
-    const int left = scldpc::kMaxLdsBytes / 4 - off;
-    int qcap = left / 2;
-    qcap &= ~3;
+    const int left = budget_bytes / 4 - off;
+    int qcap = (left / 2) & ~3;
     if (qcap > 8192) qcap = 8192;
-    if (qcap < 64) return -1;
+    if (qcap < 256) return -1;
     lay->qcap = qcap;
     lay->q0 = take(qcap);
     lay->q1 = take(qcap);
     lay->total = off;
     return 0;
+}
+
+bool packed_ok(const scldpc_code_params *p)
+{
+    return (int64_t)p->dv * p->vns_pos <= 4096 && p->dc <= 15 && p->dv <= 8;
+}
+
+// x / d == umulhi(x, magic) for every x < limit?  (monotone step function: checking the steps suffices)
+bool magic_of(int d, int64_t limit, uint32_t *magic)
+{
+    *magic = (uint32_t)((1ull << 32) / (uint32_t)d) + 1u;
+    for (int64_t q = 0; q * d < limit + d; q++) {
+        const uint64_t x0 = (uint64_t)q * d, x1 = x0 ? x0 - 1 : 0;
+        if (((x0 * *magic) >> 32) != (uint64_t)q || ((x1 * *magic) >> 32) != x1 / (uint64_t)d) return false;
+    }
+    return true;
 }
 
 }  // namespace
@@ -299,7 +384,8 @@ extern "C" int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p)
 {
     if (int rc = scldpc::check_params(p)) return rc;
     Layout lay;
-    if (make_layout(p, &lay)) return 4ll * (scldpc::nk_of(p) + scldpc::nw_of(p)) + (64 << 10);
+    if (packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &lay) == 0) return 4ll * lay.total;
+    if (make_layout<Wide>(p, scldpc::kMaxLdsBytes, &lay)) return 4ll * (scldpc::nk_of(p) + scldpc::nw_of(p)) + (64 << 10);
     return 4ll * lay.total;
 }
 
@@ -310,7 +396,7 @@ extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrial
                                      uint32_t *d_erased_bits, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || !d_counters || (ntrials > 0 && (!d_vn_adj || !d_chan_bits)))
+    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_device: null buffer or negative ntrials");
     if (d_rows && rows_cap <= 0)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_device: d_rows given but rows_cap <= 0");
@@ -320,24 +406,35 @@ extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrial
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                  "scldpc_full_bp_device: needs dc <= 15, dv <= 8, dc*n < 2^24 (got dc=%d dv=%d n=%d)",
                                  p->dc, p->dv, n);
+    const bool traj = d_rows != nullptr;
     Args a{};
-    if (make_layout(p, &a.lay))
+    // two workgroups per CU with the packed CN words when the ensemble allows it (and no trajectory rows)
+    const bool packed = !traj && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
+    if (!packed && make_layout<Wide>(p, scldpc::kMaxLdsBytes, &a.lay))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                  "scldpc_full_bp_device: nk=%d CN words + n=%d VN bits do not fit 160 KiB of LDS", nk, n);
-    a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.n = n; a.nk = nk;
+    a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.cn_lim = is_term ? nk : p->L * p->cns_pos;                    // BPT:944-948
-    a.max_it = max_it; a.rows_cap = d_rows ? rows_cap : 0;
+    a.max_it = max_it; a.rows_cap = traj ? rows_cap : 0;
+    if (!magic_of(p->vns_pos, n, &a.magic_v) || !magic_of(p->cns_pos, nk, &a.magic_c))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_full_bp_device: reciprocal division inexact for this size");
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.rows = d_rows;
     a.erased_out = d_erased_bits;
 
-    const bool traj = d_rows != nullptr;
     void (*kern)(const Args) = nullptr;
-    if (p->dv == 4) kern = traj ? full_bp_kernel<true, 4> : full_bp_kernel<false, 4>;
-    else            kern = traj ? full_bp_kernel<true, 0> : full_bp_kernel<false, 0>;
+    int block = 1024;
+    if (packed) {
+        block = 512;
+        kern = p->dv == 4 ? full_bp_kernel<Packed, false, 4, 512> : full_bp_kernel<Packed, false, 0, 512>;
+    } else if (p->dv == 4) {
+        kern = traj ? full_bp_kernel<Wide, true, 4, 1024> : full_bp_kernel<Wide, false, 4, 1024>;
+    } else {
+        kern = traj ? full_bp_kernel<Wide, true, 0, 1024> : full_bp_kernel<Wide, false, 0, 1024>;
+    }
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(block), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
 }

@@ -22,7 +22,7 @@ using namespace scldpc_dev;
 
 constexpr int kBlock = 1024;
 
-enum { S_CNT = 0, S_OVF = 3, S_NCH = 6, S_NSCAL = 16 };
+enum { S_CNT = 0, S_OVF = 3, S_REM = 6, S_NCH = 9, S_NSCAL = 16 };
 
 struct Layout {             // offsets in 32-bit words into dynamic LDS
     int cn_state, S, fbits, q0, q1, pos_cnt, pos_ss, scal, total;
@@ -104,9 +104,16 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
         const int cap = (posW == 0) ? a.init_it : a.max_it;                 // BPW:699-702
         int iter = 0, prec = n, ncur = 0;
         bool scan = true;               // a window opens with a scan of its CNs (the carried list is dropped)
+        // erasures inside the window (BPW:791-809).  Read here, where no release is in flight (the scan's
+        // snapshot barrier comes first); afterwards kept current from the per-iteration release counter so
+        // that every thread takes the same stop decision.
+        int term = 0;
+        for (int qq = posW; qq < qhi; qq++) term += pos_cnt[qq];
         for (;;) {
             uint32_t *qc = q[gen & 1], *qn = q[(gen + 1) & 1];
             int *push_cnt = &scal[S_CNT + (gen + 1) % 3], *push_ovf = &scal[S_OVF + (gen + 1) % 3];
+            int *rem_cnt = &scal[S_REM + gen % 3];
+            int removed = 0;
             auto release = [&](uint32_t c) {
                 const uint32_t w = cn_state[c];
                 if ((w >> kCntShift) != 1u) return;                         // its VN went via another CN this round
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
                 const uint32_t old = atomicAnd(&S[j >> 5], ~bit);
                 if (!(old & bit)) return;
                 atomicSub(&pos_cnt[j / V], 1);
+                removed++;
                 int32_t cc[8];
                 load_adj<DV>(adj, dv, (int)j, cc);
                 for (int i = 0; i < dv; i++) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
                     }
                 }
             };
-            if (tid == 0) { scal[S_CNT + (gen + 2) % 3] = 0; scal[S_OVF + (gen + 2) % 3] = 0; }
+            if (tid == 0) { scal[S_CNT + (gen + 2) % 3] = 0; scal[S_OVF + (gen + 2) % 3] = 0; scal[S_REM + (gen + 1) % 3] = 0; }
             if (scan) {
                 // snapshot {c in Cw : cnt == 1} into fbits first: releases of this round must not
                 // promote CNs into the round's own frontier
@@ -150,10 +158,11 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             } else {
                 for (int k = tid; k < ncur; k += kBlock) release(qc[k]);
             }
+            removed = wave_sum(removed);
+            if (lane == 0 && removed) atomicAdd(rem_cnt, removed);
             __syncthreads();                                                // end of the flooding iteration
             iters_total++;
-            int term = 0;
-            for (int qq = posW; qq < qhi; qq++) term += pos_cnt[qq];        // BPW:791-809
+            term -= *rem_cnt;           // every released VN lies inside the window
             scan = *push_ovf != 0;      // queue overflow: rebuild the frontier by a scan
             ncur = min(*push_cnt, qcap);
             gen++;
@@ -243,7 +252,7 @@ extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || !d_counters || (ntrials > 0 && (!d_vn_adj || !d_chan_bits)))
+    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: null buffer or negative ntrials");
     if (W < 1 || max_it < 0 || init_it < 0)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: need W >= 1, max_it >= 0, init_it >= 0");

@@ -64,6 +64,12 @@ class GlibcRun:
         """inizio_sim(): perm_code := identity at the start of every ε point (BPF:308-311)."""
         check(lib().scldpc_glibc_state_reset_perm(C.byref(self.p), self._state.ctypes.data))
 
+    def snapshot(self):
+        return self._state.copy()
+
+    def restore(self, snap):
+        self._state[:] = snap
+
     def next_frames(self, nframes, eps, doped=()):
         p = self.p
         vn_adj = np.empty((nframes, p.n, p.dv), dtype=np.int32)

@@ -62,6 +62,8 @@ def lib():
         L.orc_srandom.argtypes = [P(Rng), C.c_uint]
         L.orc_random.argtypes = [P(Rng)]
         L.orc_random.restype = C.c_int32
+        L.orc_fnv1a.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_fnv1a.restype = C.c_uint64
         L.orc_perm_identity.argtypes = [P(Params), i32p]
         L.orc_generate_code.argtypes = [P(Params), P(Rng), i32p, i32p, i32p, i32p]
         L.orc_channel.argtypes = [P(Params), P(Rng), C.c_double, C.c_int, P(C.c_int), u8p]

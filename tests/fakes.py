@@ -1,0 +1,61 @@
+"""Test doubles for the host-logic tests: a Simulator whose device work is replaced by a deterministic
+function of the frame index, so that sharding / ordered-stop / file-format logic can run on CPU
+(world_size 1 and 2 under gloo).  Lives in tests/: the product has no CPU path."""
+import numpy as np
+import torch
+
+from fl_scaling_sc_ldpc_amd import bp_decoding as B
+from fl_scaling_sc_ldpc_amd import engine as E
+
+
+def fake_counters(sim, frame_idx, n, L):
+    """Per-trial counter rows as a pure function of (point, frame index)."""
+    rows = np.zeros((len(frame_idx), E.NCOUNTERS), dtype=np.int32)
+    for k, f in enumerate(frame_idx):
+        h = (int(f) * 2654435761 + sim * 40503 + 12345) & 0xFFFFFFFF
+        fail = (h >> 7) % 3 != 0
+        ne = 1 + h % (n // 2) if fail else 0
+        rows[k] = [ne, (1 + h % L) if fail else 0, max(0, ne - 2 * ((h >> 3) % 2)) if fail else 0,
+                   1 if fail and ne > 2 else 0, ne % 7 if fail else 0, 5 + h % 200, 0, n // 2]
+    return rows
+
+
+def numpy_accumulate(cnt, run, stop):
+    """Literal plr_computation + willIstop loop (BPF:1503-1520, 2140-2144) in numpy."""
+    run = np.array(run, dtype=np.int64)
+    for c in cnt:
+        if stop > 0 and run[1] >= stop:
+            break
+        ne, be, ee, bee, p1, it = (int(x) for x in c[:6])
+        if ne > 0:
+            run[0] += ne; run[1] += 1; run[3] += be
+        if ee > 0:
+            run[4] += ee; run[5] += 1; run[6] += bee
+        if p1 > 0:
+            run[2] += 1
+        run[7] += 1; run[8] += it
+    return run
+
+
+class FakeSimulator(B.Simulator):
+    def __init__(self, p, batch, **kw):
+        self._frames = None
+        super().__init__(p, batch=batch, device="cpu", **kw)
+
+    def _alloc(self):
+        self.d_cnt = torch.zeros((self.batch, E.NCOUNTERS), dtype=torch.int32)
+
+    def fill_batch(self, sim, eps, frame0, nb):
+        self._frames = (sim, np.arange(frame0, frame0 + nb))
+
+    def decode_batch(self, nb, want_rows=False):
+        sim, idx = self._frames
+        self.d_cnt[:nb] = torch.from_numpy(fake_counters(sim, idx, self.p.n, self.p.L))
+        return {"counters": self.d_cnt[:nb], "rows": None, "erased": None}
+
+    def _new_run(self):
+        return torch.zeros(E.NRUN, dtype=torch.int64)
+
+    def _accumulate(self, allcnt, run, stop):
+        run.copy_(torch.from_numpy(numpy_accumulate(allcnt.numpy(), run.numpy(), stop)))
+        return run

@@ -1,0 +1,51 @@
+"""N > 1 path on CPU: two gloo ranks shard the batches of an ε point; the all-gathered counters give
+every rank the same run totals and the same cut as a single rank (device work faked, tests/fakes.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, q, cases):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fakes import FakeSimulator
+    from fl_scaling_sc_ldpc_amd import engine as E
+    p = E.make_params(4, 8, 10, 10)
+    out = []
+    for (batch, stop, max_frames) in cases:
+        sim = FakeSimulator(p, batch)
+        assert sim.world == world and sim.rank == rank
+        pt = sim.run_point(1, 0.47, stop, max_frames)
+        out.append([pt.run[k] for k in E.RUN_NAMES])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank():
+    sys.path.insert(0, HERE)
+    from fakes import fake_counters, numpy_accumulate
+    from fl_scaling_sc_ldpc_amd import engine as E
+    cases = [(8, 0, 100), (8, 17, 500), (5, 3, 64), (64, 1000, 100), (7, 40, 333)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cases)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p = E.make_params(4, 8, 10, 10)
+    for i, (batch, stop, max_frames) in enumerate(cases):
+        ref = numpy_accumulate(fake_counters(1, np.arange(max_frames), p.n, p.L), np.zeros(E.NRUN), stop).tolist()
+        assert got[0][i] == ref and got[1][i] == ref, (cases[i], got[0][i], ref)

@@ -1,0 +1,242 @@
+"""Parity tests proper (-m gpu): the HIP kernels, called through the C-ABI, against
+  (a) the golden vectors generated from the REAL reference (tests/golden, bit-exact), and
+  (b) the CPU oracle on the same seeded inputs (bit-exact: integer / bit work only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    require_gpu()
+    from fl_scaling_sc_ldpc_amd import engine
+    return engine
+
+
+def _golden_inputs(E, g, T=None):
+    m = g.meta
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
+    T = g.T if T is None else min(T, g.T)
+    adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])
+    return p, T, E.to_device(adj, ch)
+
+
+@pytest.mark.parametrize("name", golden_names(variants=("bpf", "bpt")))
+def test_full_bp_matches_reference_golden(E, name):
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p, T, (d_adj, d_ch) = _golden_inputs(E, g)
+    out = E.full_bp(p, d_adj, d_ch, max_it=g.max_it, is_term=bool(m["is_term"]),
+                    rows_cap=2048 if g.has("rows") else 0, want_erased=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for col, key in ((0, "ne"), (1, "be"), (2, "ee"), (3, "bee"), (7, "nch")):
+        assert (c[:, col] == g[key][:T]).all(), (name, key)
+    assert (c[:, 6] == 0).all() and (c[:, 4] == 0).all()
+    er = E.unpack_bits(out["erased"].cpu().numpy(), p.n)
+    assert (er.sum(axis=1) == g["ne"][:T]).all()
+    if g.has("erased"):
+        assert (er == g["erased"][:T]).all()
+    if g.has("rows"):
+        rows = out["rows"].cpu().numpy()
+        for t in range(T):
+            ref = g.rows_of(t)
+            assert c[t, 5] == len(ref) and (rows[t, :len(ref)] == ref).all(), (name, t)
+
+
+@pytest.mark.parametrize("name", golden_names(variants=("bpw",)))
+def test_sw_bp_matches_reference_golden(E, name):
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p, T, (d_adj, d_ch) = _golden_inputs(E, g)
+    out = E.sw_bp(p, d_adj, d_ch, m["W"], m["max_it"], m["init_it"], want_erased=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for col, key in ((0, "ne"), (1, "be"), (2, "ee"), (3, "bee"), (4, "p1"), (7, "nch")):
+        assert (c[:, col] == g[key][:T]).all(), (name, key)
+    assert (c[:, 6] == 0).all()
+    if g.has("erased"):
+        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
+
+
+@pytest.mark.parametrize("name", golden_names(whole_run=True))
+def test_whole_run_replay_matches_reference_run_counters(E, name):
+    """glibc stream + perm_code carried over frame to frame, decoded on the GPU, accumulated by the
+    run kernel == the reference's own users_err/frame_err/… after the same frames (BPF:2117-2144)."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
+    run_src = E.GlibcRun(p, m["seed0"])
+    adj, ch = run_src.next_frames(g.T, m["eps"])
+    d_adj, d_ch = E.to_device(adj, ch)
+    out = E.full_bp(p, d_adj, d_ch)
+    run = E.accumulate_run(out["counters"], E.new_run(), 0)
+    torch.cuda.synchronize()
+    r = dict(zip(E.RUN_NAMES, run.cpu().tolist()))
+    rc = m["run_counters"]
+    assert (r["users_err"], r["frame_err"], r["block_err"], r["users_err_exp"], r["frame_err_exp"],
+            r["block_err_exp"], r["frames"]) == (rc["users_err"], rc["frame_err"], rc["block_err"],
+                                                 rc["users_err_exp"], rc["frame_err_exp"], rc["block_err_exp"], g.T)
+    assert (out["counters"].cpu().numpy()[:, 0] == g["ne"]).all()
+
+
+@pytest.mark.parametrize("L,N,eps,doped", [(10, 10, 0.48, ()), (20, 100, 0.3, (3, 4)), (50, 1000, 0.48, ()),
+                                           (50, 1000, 0.48, (24, 25)), (7, 66, 0.9, ()), (12, 2000, 0.45, (5,)),
+                                           (5, 128, 0.0, ()), (5, 128, 1.0, (0,))])
+def test_philox_sampler_equals_cpu_twin(E, oracle, L, N, eps, doped):
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    seed, t0, T = 0x123456789ABCDEF, (1 << 33) + 5, 4
+    d_adj, d_ch = E.sample_philox(p, seed, t0, T, eps, doped)
+    torch.cuda.synchronize()
+    A, Cb = d_adj.cpu().numpy(), d_ch.cpu().numpy().view(np.uint32)
+    for t in range(T):
+        a, c = oracle.sample_philox(po, seed, t0 + t, eps, doped)
+        assert (a == A[t]).all() and (c == Cb[t]).all(), (L, N, t)
+    # every CN position holds a perfect matching: CN degrees are dc in the interior
+    deg = np.bincount(A[0].reshape(-1), minlength=p.nk).reshape(L + 3, p.cns_pos)
+    assert (deg[3:L] == 8).all() and deg.sum() == p.n * 4
+    # sharding invariance: the same trial indices drawn in a different call are identical
+    d2, c2 = E.sample_philox(p, seed, t0 + 2, 2, eps, doped)
+    assert (d2.cpu().numpy() == A[2:4]).all() and (c2.cpu().numpy().view(np.uint32) == Cb[2:4]).all()
+
+
+def _oracle_counters(oracle, po, adj, chbits, decoder, **kw):
+    g = oracle.Graph.from_vn_adj(po, adj)
+    if decoder == "full":
+        res, erased, rows = oracle.decode_bp(g, chbits, max_it=kw.get("max_it", 0), is_term=kw.get("is_term", 1),
+                                             literal=kw.get("literal", False), rows_cap=kw.get("rows_cap", 0))
+        return res, erased, rows
+    res, erased = oracle.decode_sw(g, chbits, kw["W"], kw["max_it"], kw.get("init_it", 0), literal=kw.get("literal", False))
+    return res, erased, None
+
+
+@pytest.mark.parametrize("L,N", [(50, 1000), (16, 200), (9, 24)])
+@pytest.mark.parametrize("eps", [0.05, 0.3, 0.44, 0.48, 0.52, 0.95])
+def test_full_bp_equals_oracle_on_philox_inputs(E, oracle, L, N, eps):
+    """Random seeds beyond the fixtures, incl. ε far from threshold: tiny ε floods the frontier queue
+    (overflow → scan path), large ε stops at once.  Trajectory rows and residual patterns included."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    T = 6 if N >= 1000 else 24
+    d_adj, d_ch = E.sample_philox(p, 99, int(eps * 1000) * 1000, T, eps)
+    for is_term, max_it in ((True, 0), (False, 0), (True, 3)):
+        out = E.full_bp(p, d_adj, d_ch, max_it=max_it, is_term=is_term, rows_cap=1024, want_erased=True)
+        torch.cuda.synchronize()
+        A, Cb = d_adj.cpu().numpy(), E.unpack_bits(d_ch.cpu().numpy(), p.n)
+        c, rows = out["counters"].cpu().numpy(), out["rows"].cpu().numpy()
+        er = E.unpack_bits(out["erased"].cpu().numpy(), p.n)
+        for t in range(T):
+            res, erased, orows = _oracle_counters(oracle, po, A[t], Cb[t], "full", max_it=max_it,
+                                                  is_term=int(is_term), literal=(t == 0 and N < 1000), rows_cap=1024)
+            assert c[t, :4].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                         res["num_blocks_err_exp"]], (L, N, eps, is_term, max_it, t)
+            assert c[t, 5] == res["iterations"] and c[t, 6] == 0 and c[t, 7] == Cb[t].sum()
+            assert (er[t] == erased).all()
+            k = res["iterations"]
+            got = rows[t, :k]
+            assert (got[:, 0] == orows["deg1"]).all() and (got[:, 1] == orows["recovered"]).all() \
+                and (got[:, 2] == orows["first_pos"]).all(), (L, N, eps, is_term, max_it, t)
+
+
+@pytest.mark.parametrize("L,N,W,max_it,init_it", [(50, 1000, 20, 6, 60), (50, 1000, 10, 20, 0), (16, 200, 5, 3, 9),
+                                                  (16, 200, 30, 50, 0), (9, 24, 1, 1, 1), (9, 24, 4, 2, 0)])
+@pytest.mark.parametrize("eps", [0.1, 0.42, 0.47, 0.6])
+def test_sw_bp_equals_oracle_on_philox_inputs(E, oracle, L, N, W, max_it, init_it, eps):
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    T = 5 if N >= 1000 else 20
+    d_adj, d_ch = E.sample_philox(p, 7, int(eps * 1000) * 1000 + W, T, eps)
+    out = E.sw_bp(p, d_adj, d_ch, W, max_it, init_it, want_erased=True)
+    torch.cuda.synchronize()
+    A, Cb = d_adj.cpu().numpy(), E.unpack_bits(d_ch.cpu().numpy(), p.n)
+    c = out["counters"].cpu().numpy()
+    er = E.unpack_bits(out["erased"].cpu().numpy(), p.n)
+    for t in range(T):
+        res, erased, _ = _oracle_counters(oracle, po, A[t], Cb[t], "sw", W=W, max_it=max_it, init_it=init_it,
+                                          literal=(t == 0))
+        assert c[t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                     res["num_blocks_err_exp"], res["num_erasures_p1"]], (L, N, W, eps, t)
+        assert c[t, 5] == res["iterations"] and c[t, 6] == 0
+        assert (er[t] == erased).all()
+
+
+def test_generic_dv_path(E, oracle):
+    """(3,6) ensemble: the non-int4 adjacency path of all three kernels."""
+    import torch
+    p = E.make_params(3, 6, 14, 60)
+    po = oracle.Params(3, 6, 14, p.cns_pos, p.vns_pos)
+    d_adj, d_ch = E.sample_philox(p, 3, 0, 16, 0.4)
+    A, Cb = d_adj.cpu().numpy(), d_ch.cpu().numpy().view(np.uint32)
+    for t in range(4):
+        a, c = oracle.sample_philox(po, 3, t, 0.4)
+        assert (a == A[t]).all() and (c == Cb[t]).all()
+    out = E.full_bp(p, d_adj, d_ch, rows_cap=256)
+    sw = E.sw_bp(p, d_adj, d_ch, 5, 4, 8)
+    torch.cuda.synchronize()
+    bits = E.unpack_bits(Cb, p.n)
+    for t in range(16):
+        res, _, orows = _oracle_counters(oracle, po, A[t], bits[t], "full", rows_cap=256)
+        assert out["counters"][t, :4].tolist() == [res["num_erasures"], res["num_blocks_err"],
+                                                   res["num_erasures_exp"], res["num_blocks_err_exp"]]
+        assert (out["rows"][t, :res["iterations"], 0].cpu().numpy() == orows["deg1"]).all()
+        res, _, _ = _oracle_counters(oracle, po, A[t], bits[t], "sw", W=5, max_it=4, init_it=8)
+        assert sw["counters"][t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                                  res["num_blocks_err_exp"], res["num_erasures_p1"]]
+
+
+def test_edge_cases(E, oracle):
+    import torch
+    p = E.make_params(4, 8, 10, 40)
+    # empty batch: nothing launched, nothing touched
+    d_adj = torch.empty((0, p.n, 4), dtype=torch.int32, device="cuda")
+    d_ch = torch.empty((0, p.nw), dtype=torch.int32, device="cuda")
+    assert E.full_bp(p, d_adj, d_ch)["counters"].shape == (0, 8)
+    assert E.sw_bp(p, d_adj, d_ch, 3, 2)["counters"].shape == (0, 8)
+    # nothing erased / everything erased
+    d_adj, d_ch = E.sample_philox(p, 1, 0, 3, 0.0)
+    c = E.full_bp(p, d_adj, d_ch)["counters"].cpu().numpy()
+    assert (c[:, :5] == 0).all() and (c[:, 5] == 1).all() and (c[:, 7] == 0).all()
+    d_adj, d_ch = E.sample_philox(p, 1, 0, 3, 1.0)
+    c = E.full_bp(p, d_adj, d_ch)["counters"].cpu().numpy()
+    assert (c[:, 7] == p.n).all() and (c[:, 1] == p.L).all()
+    # even a fully erased word loses a few VNs: boundary CNs of degree 1 resolve their only neighbour
+    po = oracle.Params(4, 8, 10, p.cns_pos, p.vns_pos)
+    A = d_adj.cpu().numpy()
+    for t in range(3):
+        res, _, _ = oracle.decode_bp(oracle.Graph.from_vn_adj(po, A[t]), np.ones(p.n, np.uint8), literal=True)
+        assert c[t, :4].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                     res["num_blocks_err_exp"]] and c[t, 5] == res["iterations"]
+        assert res["num_erasures"] < p.n
+    # ragged n (not a multiple of 32) is covered by (9,24) above; ensembles beyond the LDS budget are refused
+    big = E.make_params(4, 8, 50, 10000)
+    with pytest.raises(E.ScldpcError, match="160 KiB"):
+        E.full_bp(big, torch.empty((1, big.n, 4), dtype=torch.int32, device="cuda"),
+                  torch.empty((1, big.nw), dtype=torch.int32, device="cuda"))
+
+
+def test_accumulate_run_ordered_stop(E):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fakes import fake_counters, numpy_accumulate
+    import torch
+    for T in (1, 5, 1023, 1024, 1025, 5000):
+        cnt = fake_counters(3, np.arange(T), 400, 10)
+        d = torch.from_numpy(cnt).cuda()
+        for stop in (0, 1, 7, 333, 100000):
+            run = E.new_run()
+            run[1] = 2                                        # a run already holding 2 frame errors
+            E.accumulate_run(d, run, stop)
+            ref = np.zeros(E.NRUN, dtype=np.int64); ref[1] = 2
+            assert run.cpu().tolist() == numpy_accumulate(cnt, ref, stop).tolist(), (T, stop)

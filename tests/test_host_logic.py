@@ -1,0 +1,80 @@
+"""Host orchestration of the bp_decoding mirror: file names and row formats (risultati, BPF:458-519),
+argv contract incl. the doped-position quirk (BPF:2083-2091), ε grid (BPF:55-61,301) and the ordered stop
+rule under batching (BPF:440-451, 2117-2144) — with the device work replaced by tests/fakes.py."""
+import numpy as np
+import pytest
+
+from fakes import FakeSimulator, fake_counters, numpy_accumulate
+from fl_scaling_sc_ldpc_amd import bp_decoding as B
+from fl_scaling_sc_ldpc_amd import engine as E
+
+
+def test_filenames_match_reference_sprintf():
+    p = E.make_params(4, 8, 50, 1000)
+    assert B.result_filename("bp_lim_iter", p, 0, 350, 0, 3) == "SC_LDPC_4_8_L50_M500_BP_SW0_350it_Random_BLER_3.dat"
+    assert B.result_filename("sw_lim_iter", p, 20, 6, 60, 0) == "SC_LDPC_4_8_L50_M500_BP_SW20_6it_60init_Random_BLER_0.dat"
+    p5 = E.make_params(4, 8, 50, 5000)
+    assert B.traj_filename(p5, 0.46, 1000000, True, 0) == \
+        "trajectories_0.4600_terminated_SC_LDPC_4_8_L50_M2500_BP_Full_1000000it_Random_BLER_0.dat"
+    assert "truncated" in B.traj_filename(p5, 0.46, 5, False, 7)
+
+
+def test_risultati_row_format_parses_like_the_notebook(tmp_path):
+    run = [123456, 921, 0, 29860, 120000, 900, 29000, 1000, 200000]
+    pt = B.PointResult(0.48, 50000, 50, run)
+    path = tmp_path / "r.dat"
+    B.write_risultati(str(path), 0, pt)
+    B.write_risultati(str(path), 1, B.PointResult(0.47875, 50000, 50, run))
+    lines = open(path).read().split("\n")
+    assert lines[0] == B.RISULTATI_HEADER.strip()
+    # "%f %e %e %e %e %e %e %d×9" (BPF:499-515)
+    assert lines[1] == ("0.480000 2.469120e-03 9.210000e-01 5.972000e-01 2.400000e-03 9.000000e-01 5.800000e-01 "
+                        "50000 50 1000 123456 921 29860 120000 900 29000")
+    tab = np.loadtxt(str(path), skiprows=1)                 # the notebook reads columns 0,4,5,6 (NB cell 36:5)
+    assert tab.shape == (2, 16) and tab[1, 0] == pytest.approx(0.47875)
+
+
+def test_eps_grid_defaults_are_the_shipped_defines():
+    g = B.DEFAULTS["bp_lim_iter"]["grid"]
+    assert [round(g.eps(s), 5) for s in (0, 1, 25)] == [0.48, 0.47875, 0.44875] and g.num_points == 26
+    g = B.DEFAULTS["sw_lim_iter"]["grid"]
+    assert (g.eps(0), g.num_points, g.min_frame_err, g.max_frames) == (0.475, 18, 1000, 1000)
+    g = B.DEFAULTS["bp_traj"]["grid"]
+    assert (g.eps(0), g.num_points, g.min_frame_err, g.max_frames) == (0.46, 1, 500, 500)
+    assert B.DEFAULTS["bp_traj"]["N"] == 5000             # Def_M = 2500 (BPT:25)
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64, 1000])
+@pytest.mark.parametrize("stop,max_frames", [(0, 300), (25, 300), (1000, 300), (1, 50)])
+def test_ordered_stop_is_independent_of_batch_size(batch, stop, max_frames):
+    p = E.make_params(4, 8, 10, 10)
+    sim = FakeSimulator(p, batch)
+    pt = sim.run_point(2, 0.47, stop, max_frames)
+    ref = numpy_accumulate(fake_counters(2, np.arange(max_frames), p.n, p.L), np.zeros(E.NRUN), stop)
+    assert [pt.run[k] for k in E.RUN_NAMES] == ref.tolist()
+    if stop and ref[1] >= stop:
+        assert pt.run["frame_err"] == stop                  # cut exactly at the tripping frame
+
+
+def test_argv_quirk_first_doped_position_is_max_it(tmp_path, monkeypatch):
+    """main_terminated fills doped_positions from argv[4] on — argv[4] is MAX_IT (BPF:2083-2091)."""
+    seen = {}
+
+    class Spy(FakeSimulator):
+        def __init__(self, p, **kw):
+            seen.update(kw, p=p)
+            kw.pop("device", None)
+            super().__init__(p, kw.pop("batch"), **kw)
+
+    monkeypatch.setattr(B, "Simulator", Spy)
+    B.bp_lim_iter(["5", "0", "2", "7", "9", "--L", "12", "--N", "10", "--num-points", "2", "--max-frames", "40",
+                   "--batch", "16", "--seed", "1", "--outdir", str(tmp_path), "--quiet"])
+    assert seen["doped"] == [7, 9] and seen["max_it"] == 7 and seen["decoder"] == "full"
+    out = tmp_path / "SC_LDPC_4_8_L12_M5_BP_SW0_7it_Random_BLER_5.dat"
+    rows = open(out).read().strip().split("\n")
+    assert len(rows) == 3 and rows[1].startswith("0.480000 ") and rows[2].startswith("0.478750 ")
+    assert rows[1].split()[9] == "40"                        # f = frames consumed
+    B.sw_lim_iter(["0", "4", "0", "3", "0", "--L", "12", "--N", "10", "--num-points", "1", "--max-frames", "8",
+                   "--batch", "16", "--seed", "1", "--outdir", str(tmp_path), "--quiet"])
+    assert seen["decoder"] == "sw" and seen["init_it"] == 3 and seen["W"] == 4       # INIT_IT 0 ⇒ MAX_IT (BPW:2101)
+    assert (tmp_path / "SC_LDPC_4_8_L12_M5_BP_SW4_3it_3init_Random_BLER_0.dat").exists()

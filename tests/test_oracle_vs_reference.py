@@ -1,0 +1,31 @@
+"""Oracle vs the REAL reference on seeds the fixtures do not hold.  Runs only where oracle/_ref was
+built from /root/reference (this container); elsewhere the committed fixtures are the pin."""
+import numpy as np
+import pytest
+
+CASES = [("bpf", 5, 10, (0, 1), {}), ("bpf", 3, 10, (0, 1), {}), ("bpf", 5, 10, (0, 1), dict(max_it=2)),
+         ("bpt", 5, 10, (0, 1), dict(is_term=0)), ("bpt", 50, 20, (0, 1), dict(is_term=1)),
+         ("bpw", 5, 10, (2, 3), dict(W=3, max_it=2, init_it=4)), ("bpw", 50, 20, (2, 3), dict(W=5, max_it=3, init_it=9)),
+         ("bpfsw", 5, 10, (4,), dict(W=4, max_it=3)), ("bpw", 3, 10, (2, 3), dict(W=4, max_it=5, init_it=9))]
+
+
+@pytest.mark.parametrize("variant,M,L,decoders,kw", CASES)
+def test_fresh_seeds(oracle, variant, M, L, decoders, kw):
+    O = oracle
+    if not O.have_ref(variant, M, L):
+        pytest.skip("oracle/_ref not built (no /root/reference here): golden fixtures are the pin")
+    rng = np.random.RandomState(hash((variant, M, L)) % 2**31)
+    p = O.Params(4, 8, L, M, 2 * M)
+    for eps in (0.33, 0.46, 0.5, 0.58):
+        seed0 = int(rng.randint(1, 2**30))
+        T = 60 if M <= 5 else 12
+        hdr, trials, _ = O.run_ref(variant, M, L, T, seed0, eps, **kw)
+        for tr in trials:
+            for dec in decoders:
+                o = O.trial(p, tr["seed"], eps, decoder=dec, W=kw.get("W", 0), max_it=kw.get("max_it", 0),
+                            init_it=kw.get("init_it", 0), is_term=kw.get("is_term", 1), rows_cap=4096)
+                assert (o["nch"], o["hg"], o["hc"], o["he"]) == (tr["nch"], tr["hg"], tr["hc"], tr["he"])
+                assert (o["num_erasures"], o["num_blocks_err"], o["num_erasures_exp"], o["num_blocks_err_exp"],
+                        o["num_erasures_p1"]) == (tr["ne"], tr["be"], tr["ee"], tr["bee"], tr["p1"])
+                if "rows" in tr:
+                    assert len(o["rows"]) == len(tr["rows"]) and (o["rows"] == tr["rows"]).all()

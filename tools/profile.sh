@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root.  Collects, for the bench workload:
+#   1. rocprofv3 --kernel-trace --stats            → per-kernel time
+#   2. rocprofv3 --pmc FETCH_SIZE  (own pass)       → HBM read bytes per dispatch  (×2 on gfx950, see guide)
+#   3. rocprofv3 --pmc WRITE_SIZE  (own pass)       → HBM write bytes per dispatch
+# Raw CSVs land in gpurun_out/prof_$TAG/; tools/summarize_prof.py condenses them into profiles/.
+set -e
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
+echo "write done"
+find $OUT -name "*.csv" | head -20
