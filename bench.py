@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trials per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +112,7 @@ def main():
     from fl_scaling_sc_ldpc_amd import engine as E
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch
-    d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int32, device=dev)
+    d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int32 if a.adj32 else torch.int16, device=dev)
     d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
     d_cnt = torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev)
     run = E.new_run(dev)
@@ -173,7 +174,8 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload_name(), "trials_per_gpu_per_step": B,
                        "step": "device sample (code+channel) -> decodeBP -> plr_computation",
-                       "rng": "philox4x32-10 keyed by (seed, trial)", "parallelism": f"trial-sharded x{world}"},
+                       "rng": "philox4x32-10 keyed by (seed, trial)",
+                       "adjacency": "int32 global ids" if a.adj32 else "uint16 position-local ids", "parallelism": f"trial-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "full_bp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_trial": b_alg, "trials_per_launch": B, "ms_per_launch": ms_bp},

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libscldpc_hip.so")
+# SCLDPC_LIB_PATH: diagnostics only (tools/stamps.py loads the stamped build of the same sources)
+LIB_PATH = os.environ.get("SCLDPC_LIB_PATH") or os.path.join(HERE, "libscldpc_hip.so")
 
 NCOUNTERS = 8
 NRUN = 9
@@ -25,6 +26,7 @@ EXPORTS = (
     "scldpc_glibc_state_reset_perm", "scldpc_sample_glibc_next_host",
     "scldpc_sample_philox_device", "scldpc_full_bp_device", "scldpc_sw_bp_device",
     "scldpc_accumulate_run_device", "scldpc_full_bp_lds_bytes",
+    "scldpc_sample_philox_device_adj16", "scldpc_full_bp_device_adj16", "scldpc_sw_bp_device_adj16",
 )
 
 
@@ -83,6 +85,9 @@ def lib():
     L.scldpc_sample_philox_device.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes
+    L.scldpc_full_bp_device_adj16.argtypes = L.scldpc_full_bp_device.argtypes
+    L.scldpc_sw_bp_device_adj16.argtypes = L.scldpc_sw_bp_device.argtypes
     L.scldpc_accumulate_run_device.argtypes = [i32, vp, i64, vp, vp]
     L.scldpc_full_bp_lds_bytes.argtypes = [pp]
     L.scldpc_full_bp_lds_bytes.restype = i64

@@ -40,7 +40,7 @@ struct Args {
     int dv, L, vns_pos, cns_pos, n, nk, cn_lim, max_it, rows_cap;
     uint32_t magic_v, magic_c;      // floor(2^32/d)+1: x/d == umulhi(x, magic) for the ranges used here
     Layout lay;
-    const int32_t *vn_adj;
+    const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     const uint32_t *chan;
     int32_t *counters;
     int32_t *rows;
@@ -64,10 +64,11 @@ struct Wide {
         const uint32_t w = st[c];
         return (w >> kCntShift) == 1u ? (int)(w & kSumMask) : -1;
     }
-    static __device__ __forceinline__ uint32_t remove(uint32_t *st, int c, const Vn &v, int, int)   // returns old cnt
+    static __device__ __forceinline__ uint32_t remove_cnt(uint32_t *st, int c, const Vn &v, int, int)   // returns old cnt
     {
         return atomicSub(&st[c], kCntOne + (uint32_t)v.j) >> kCntShift;
     }
+    static __device__ __forceinline__ void remove_fold(uint32_t *, int, const Vn &, int, int) {}
     // partner of v at CN c if cnt == 2, else -1
     static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int, const Args &)
     {
@@ -98,18 +99,20 @@ struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of wo
     }
     static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &a)
     {
-        // cnt and fold are updated by two atomics (remove(): count first, fold second).  The only update a
+        // cnt and fold are updated by two atomics (count first, fold second).  The only update a
         // CN of the CURRENT frontier can see in its round is the removal of its own VN, which drops cnt to 0
         // before it touches the fold — so a frontier CN read with cnt == 1 carries exactly its one neighbour.
         const uint32_t h = half(st, c);
         return (h >> 12) == 1u ? lid_to_vn(c, h & 0xFFFu, a) : -1;
     }
-    static __device__ __forceinline__ uint32_t remove(uint32_t *st, int c, const Vn &v, int i, int V)
+    static __device__ __forceinline__ uint32_t remove_cnt(uint32_t *st, int c, const Vn &, int, int)
     {
         const int sh = (c & 1) * 16;
-        const uint32_t o = (atomicSub(&st[c >> 1], 0x1000u << sh) >> (sh + 12)) & 0xFu;
-        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << sh);
-        return o;
+        return (atomicSub(&st[c >> 1], 0x1000u << sh) >> (sh + 12)) & 0xFu;
+    }
+    static __device__ __forceinline__ void remove_fold(uint32_t *st, int c, const Vn &v, int i, int V)
+    {
+        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << ((c & 1) * 16));
     }
     static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int i, const Args &a)
     {
@@ -118,7 +121,7 @@ struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of wo
     }
 };
 
-template <class ST, bool TRAJ, int DV, int BLOCK>
+template <class ST, bool TRAJ, int DV, bool A16, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
     const int trial = blockIdx.x;
     const int n = a.n, nk = a.nk, dv = (DV ? DV : a.dv), cn_lim = a.cn_lim, nw = a.lay.nw, qcap = a.lay.qcap;
     const int V = a.vns_pos;
-    const int32_t *adj = a.vn_adj + (size_t)trial * n * dv;
+    const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
     const uint32_t *ch = a.chan + (size_t)trial * nw;
     auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
 
@@ -150,6 +153,8 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
     if (tid < S_NSCAL) scal[tid] = 0;
     for (int i = tid; i < a.L; i += BLOCK) { pos_cnt[i] = 0; pos_ss[i] = 0; }
     __syncthreads();
+    STAMP_DECL
+    STAMP(0);                                                       // clear + channel load
     ne_local = wave_sum(ne_local);
     if (lane == 0 && ne_local) atomicAdd(&scal[S_NE], ne_local);
 
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
             const int j = j0 + u * BLOCK;
             er[u] = false;
             if (j < n) {
-                load_adj<DV>(adj, dv, j, c[u]);
+                load_adj<DV, A16>(adj, dv, j, (int)__umulhi((uint32_t)j, a.magic_v), a.cns_pos, c[u]);
                 er[u] = (U[j >> 5] >> (j & 31)) & 1u;
             }
         }
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
         }
     }
     __syncthreads();
+    STAMP(1);                                                       // build
 
     int ne = scal[S_NE];
     const int nch = ne;
@@ -193,21 +199,27 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
         auto release = [&](int c) {
             const int j = ST::lone_vn(cn_state, c, a);
             if (j < 0) return;                                      // its VN was just released via another CN
-            const uint32_t bit = 1u << (j & 31);
+            const Vn v = make_vn(j);
+            int32_t cc[8];
+            load_adj<DV, A16>(adj, dv, j, v.pos, a.cns_pos, cc);    // issued before the ownership test: its latency
+            const uint32_t bit = 1u << (j & 31);                    // overlaps the LDS round trip below
             const uint32_t old = atomicAnd(&U[j >> 5], ~bit);
             if (!(old & bit)) return;                               // lost the race for VN j
             removed++;
-            const Vn v = make_vn(j);
-            int32_t cc[8];
-            load_adj<DV>(adj, dv, j, cc);
-            for (int i = 0; i < dv; i++) {
-                const int c2 = cc[i];
-                const uint32_t o = ST::remove(cn_state, c2, v, i, V);
-                if (c2 < cn_lim) {
-                    drops += (o == 1u);
-                    if (o == 2u) {                                  // 2 → 1: candidate for the next round
+            uint32_t o[8];
+#pragma unroll
+            for (int i = 0; i < (DV ? DV : 8); i++)                 // the dv returning atomics go out back to back
+                if (i < dv) o[i] = ST::remove_cnt(cn_state, cc[i], v, i, V);
+#pragma unroll
+            for (int i = 0; i < (DV ? DV : 8); i++)
+                if (i < dv) ST::remove_fold(cn_state, cc[i], v, i, V);
+#pragma unroll
+            for (int i = 0; i < (DV ? DV : 8); i++) {
+                if (i < dv && cc[i] < cn_lim) {
+                    drops += (o[i] == 1u);
+                    if (o[i] == 2u) {                               // 2 → 1: candidate for the next round
                         const int idx = atomicAdd(&scal[S_PUSH + g], 1);
-                        if (idx < qcap) qn[idx] = (uint32_t)c2; else scal[S_OVF + g] = 1;
+                        if (idx < qcap) qn[idx] = (uint32_t)cc[i]; else scal[S_OVF + g] = 1;
                     }
                 }
             }
@@ -248,11 +260,17 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
         } else {
             for (int k = tid; k < ncur; k += BLOCK) release((int)qc[k]);
         }
-        removed = wave_sum(removed);
-        drops = wave_sum(drops);
-        if (lane == 0 && removed) atomicAdd(&scal[S_REM + g], removed);
-        if (lane == 0 && drops) atomicAdd(&scal[S_DROP + g], drops);
+        STAMP(2);                                                   // release
+        {   // one DPP reduction for both counts (each < 2^16 per wave)
+            const uint32_t both = wave_inclusive_scan(((uint32_t)removed << 16) | (uint32_t)drops);
+            if (lane == 63 && both) {
+                if (both >> 16) atomicAdd(&scal[S_REM + g], (int)(both >> 16));
+                if (both & 0xFFFFu) atomicAdd(&scal[S_DROP + g], (int)(both & 0xFFFFu));
+            }
+        }
+        STAMP(3);                                                   // wave reductions
         __syncthreads();                                            // end of flooding iteration `iter`
+        STAMP(4);                                                   // barrier wait
 
         // ---- bookkeeping, identical in every thread ----------------------------------------
         const int deg1 = nfront + ((TRAJ && iter == 0) ? scal[S_EXTRA0] : 0);
@@ -290,8 +308,10 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
         ncur = scan ? 0 : scal[S_PUSH + g];
         iter++;
         if (a.max_it > 0 && iter >= a.max_it) break;                // BPF:1065
+        STAMP(5);                                                   // bookkeeping
     }
     __syncthreads();
+    STAMP(5);
 
     // ---- per-position erasure counts + size-2 stopping sets (BPF:1067-1133) -----------------
     if (ne > 0) {
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
                 const Vn v = make_vn(w * 32 + b);
                 atomicAdd(&pos_cnt[v.pos], 1);
                 int32_t cc[8];
-                load_adj<DV>(adj, dv, v.j, cc);
+                load_adj<DV, A16>(adj, dv, v.j, v.pos, a.cns_pos, cc);
                 bool pair = true;
                 int partner = -1;
                 for (int i = 0; i < dv; i++) {
@@ -316,6 +336,8 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
         }
     }
     __syncthreads();
+    STAMP(6);                                                       // final counts + expurgation
+    STAMP_FLUSH();
     if (a.erased_out)
         for (int w = tid; w < nw; w += BLOCK) a.erased_out[(size_t)trial * nw + w] = U[w];
     if (tid == 0) {
@@ -389,11 +411,10 @@ extern "C" int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p)
     return 4ll * lay.total;
 }
 
-extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
-                                     const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
-                                     int32_t max_it, int32_t is_term,
-                                     int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                                     uint32_t *d_erased_bits, void *stream)
+static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+                          const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                          int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                          uint32_t *d_erased_bits, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
     if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
@@ -423,18 +444,37 @@ extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrial
 
     void (*kern)(const Args) = nullptr;
     int block = 1024;
-    if (packed) {
-        block = 512;
-        kern = p->dv == 4 ? full_bp_kernel<Packed, false, 4, 512> : full_bp_kernel<Packed, false, 0, 512>;
-    } else if (p->dv == 4) {
-        kern = traj ? full_bp_kernel<Wide, true, 4, 1024> : full_bp_kernel<Wide, false, 4, 1024>;
-    } else {
-        kern = traj ? full_bp_kernel<Wide, true, 0, 1024> : full_bp_kernel<Wide, false, 0, 1024>;
-    }
+    const bool d4 = p->dv == 4;
+#define PICK(ST, TRAJ, BLK) (d4 ? (adj16 ? full_bp_kernel<ST, TRAJ, 4, true, BLK> : full_bp_kernel<ST, TRAJ, 4, false, BLK>) \
+                                : (adj16 ? full_bp_kernel<ST, TRAJ, 0, true, BLK> : full_bp_kernel<ST, TRAJ, 0, false, BLK>))
+    if (packed) { block = 512; kern = PICK(Packed, false, 512); }
+    else if (traj) kern = PICK(Wide, true, 1024);
+    else kern = PICK(Wide, false, 1024);
+#undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(block), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                                     const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                     int32_t max_it, int32_t is_term,
+                                     int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                                     uint32_t *d_erased_bits, void *stream)
+{
+    return launch_full_bp(p, ntrials, d_vn_adj, false, d_chan_bits, max_it, is_term, d_counters, d_rows, rows_cap,
+                          d_erased_bits, stream);
+}
+
+extern "C" int scldpc_full_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                           const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                           int32_t max_it, int32_t is_term,
+                                           int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                                           uint32_t *d_erased_bits, void *stream)
+{
+    return launch_full_bp(p, ntrials, d_vn_adj16, true, d_chan_bits, max_it, is_term, d_counters, d_rows, rows_cap,
+                          d_erased_bits, stream);
 }

@@ -12,13 +12,16 @@
 // A permutation is the rank of each socket's 32-bit key (ties by socket index), computed in LDS by
 // one counting pass over the key's top bits plus a tiny in-bucket comparison (buckets hold ~1 key).
 // One workgroup samples one trial: it walks the D positions, keeps the last dv permutations in an
-// LDS ring, and emits VN position p-dv+1 as whole 16-byte rows, so HBM sees only full-line stores.
+// LDS ring, and emits VN position p-dv+1 as whole rows (16 B as int32 CN ids, or 8 B as uint16
+// position-local CN ids), so HBM sees only full-line stores.
 // The exact-replay sampler (glibc stream, identical seeds) is glibc_sampler.cpp.
 #include "common.h"
+#include "kernel_util.h"
 
 namespace {
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
 constexpr int kMaxDoped = 32;
 
 struct SArgs {
@@ -29,7 +32,8 @@ struct SArgs {
     unsigned long long trial0;
     uint32_t thresh;            // erased iff (draw >> 1) < thresh
     int off_gkey, off_gidx, off_win, off_wsum;   // LDS offsets in 32-bit words
-    int32_t *vn_adj;
+    int32_t *vn_adj;            // int32 [T][n][dv]  (or)
+    uint16_t *vn_adj16;         // uint16 [T][n][dv], CN index local to its position
     uint32_t *chan;
 };
 
@@ -46,8 +50,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// KMAX = Philox calls per thread per permutation (4 sockets each)
-template <int KMAX>
+using scldpc_dev::wave_inclusive_scan;
+
+// KMAX = Philox calls per thread per permutation (4 sockets each); ROWS = 64-counter rows each wave scans
+template <int KMAX, int ROWS, bool ADJ16>
 __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
 {
     extern __shared__ uint32_t lds[];
@@ -56,17 +62,19 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
     uint16_t *gidx = reinterpret_cast<uint16_t *>(lds + a.off_gidx);   // S socket ids, same order
     uint16_t *win = reinterpret_cast<uint16_t *>(lds + a.off_win);     // ring of dv × S CN-local ids
     uint32_t *wsum = lds + a.off_wsum;                              // per-wave totals for the scan
+    uint32_t *wpre = wsum + 32;                                     // [wave][16] exclusive prefix of wsum, one copy per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long trial = a.trial0 + blockIdx.x;
     const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     const int S = a.S, nb = a.nb, dv = a.dv;
     const int ncalls = (S + 3) >> 2;
-    int32_t *adj = a.vn_adj + (size_t)blockIdx.x * a.n * dv;
 
+    STAMP_DECL
     for (int p = 0; p < a.D; p++) {
         for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
         __syncthreads();
+        STAMP(0);                                   // clear
 
         // ---- keys + bucket histogram; the atomic's return value is the arrival slot in the bucket
         uint32_t key[KMAX * 4], slot[KMAX * 4];
@@ -84,44 +92,41 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
             }
         }
         __syncthreads();
+        STAMP(1);                                   // keys + histogram
 
-        // ---- exclusive scan of the bucket counts.  Each wave scans its own nb/8 contiguous slice
-        //      (64 consecutive counters per step: conflict-free); the slice bases go to wpre[] and are
-        //      added by the readers:  base(b) = hist[b] + wpre[b >> lgchunk].
+        // ---- exclusive scan of the bucket counts.  Each wave owns nb/16 contiguous counters = ROWS rows of
+        //      64; the rows are scanned independently (DPP) and chained by their totals; the slice bases go to
+        //      wsum[] and are added by the readers:  base(b) = hist[b] + Σ_{w < b>>lgchunk} wsum[w].
         {
-            const int chunk = nb >> 3;
-            uint32_t carry = 0;
-            for (int i = 0; i < chunk; i += 64) {
-                const int idx = wave * chunk + i + lane;
-                const uint32_t v = hist[idx];
-                uint32_t inc = v;
+            const int base = wave * (ROWS * 64) + lane;
+            uint32_t v[ROWS], inc[ROWS];
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t y = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += y;
-                }
-                hist[idx] = carry + inc - v;
-                carry += __shfl(inc, 63, 64);
+            for (int r = 0; r < ROWS; r++) v[r] = hist[base + r * 64];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                hist[base + r * 64] = carry + inc[r] - v[r];
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
             }
             if (lane == 0) wsum[wave] = carry;
         }
         __syncthreads();
-        uint32_t wpre[8];
+        STAMP(2);                                   // scan
+        // exclusive prefix of the 16 slice totals: every wave scans them itself (lanes 0-15, one DPP row) into
+        // its own 16 words of LDS — no further barrier, and a 2-read bucket base instead of a select chain
         {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int w = 0; w < 8; w++) { wpre[w] = acc; acc += wsum[w]; }
+            const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t inc = wave_inclusive_scan(t);
+            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
         }
         auto bucket_base = [&](uint32_t b) -> uint32_t {
-            if (b >= (uint32_t)nb) return (uint32_t)S;
-            const uint32_t h = hist[b], w = b >> a.lgchunk;
-            uint32_t add = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) add = (w == (uint32_t)k) ? wpre[k] : add;
-            return h + add;
+            return b >= (uint32_t)nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
         };
 
         // ---- group (key, socket) by bucket
+        uint32_t g0s[KMAX * 4], g1s[KMAX * 4];
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
             const int q = tid + k * kThreads;
@@ -129,54 +134,80 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
             for (int u = 0; u < 4; u++) {
                 const int s = q * 4 + u;
                 if (q < ncalls && s < S) {
-                    const uint32_t g = bucket_base(key[k * 4 + u] >> a.shift) + slot[k * 4 + u];
+                    const uint32_t b = key[k * 4 + u] >> a.shift;
+                    g0s[k * 4 + u] = bucket_base(b);
+                    g1s[k * 4 + u] = bucket_base(b + 1);
+                    const uint32_t g = g0s[k * 4 + u] + slot[k * 4 + u];
                     gkey[g] = key[k * 4 + u];
                     gidx[g] = (uint16_t)s;
                 }
             }
         }
         __syncthreads();
+        STAMP(3);                                   // group
 
-        // ---- rank = bucket base + #(smaller (key, socket) pairs in the bucket); CN-local id = rank / dc
+        // ---- rank = bucket base + #(smaller (key, socket) pairs in the bucket); CN-local id = rank / dc.
+        //      The thread's keys walk their buckets in one fused loop so that their LDS latencies overlap;
+        //      one 32-bit read per bucket-mate, the socket id only on a key tie.
         uint16_t *wp = win + (size_t)(p % dv) * S;
+        {
+            uint32_t rank[KMAX * 4], span = 0;
 #pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-            const int q = tid + k * kThreads;
+            for (int e = 0; e < KMAX * 4; e++) {
+                const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
+                rank[e] = g0s[e];
+                if (s < S) span = max(span, g1s[e] - g0s[e]); else g1s[e] = g0s[e] = 0;
+            }
+            for (uint32_t step = 0; step < span; step++) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int s = q * 4 + u;
-                if (q < ncalls && s < S) {
-                    const uint32_t kk = key[k * 4 + u], b = kk >> a.shift;
-                    const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1);
-                    uint32_t rank = g0;
-                    for (uint32_t g = g0; g < g1; g++) {
+                for (int e = 0; e < KMAX * 4; e++) {
+                    const uint32_t g = g0s[e] + step;
+                    if (g < g1s[e] && step != slot[e]) {            // slot[e] is this key's own place in the bucket
                         const uint32_t k2 = gkey[g];
-                        rank += (k2 < kk) || (k2 == kk && gidx[g] < (uint16_t)s);
+                        const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
+                        rank[e] += (k2 < key[e]) || (k2 == key[e] && gidx[g] < (uint16_t)s);
                     }
-                    wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < KMAX * 4; e++) {
+                const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
+                if (s < S) wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank[e] >> a.dc_shift : rank[e] / (uint32_t)a.dc);
             }
         }
         __syncthreads();
+        STAMP(4);                                   // rank
 
         // ---- VN position q = p-dv+1 now has all its dv permutations in the ring (BPF:1703-1716)
         const int qpos = p - (dv - 1);
         if (qpos >= 0) {
             for (int t = tid; t < a.vns_pos; t += kThreads) {
-                const int j = qpos * a.vns_pos + t;
+                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
                 if (dv == 4) {
-                    int4 v;
-                    v.x = (qpos + 0) * a.cns_pos + win[(size_t)((qpos + 0) % 4) * S + 4 * t + 0];
-                    v.y = (qpos + 1) * a.cns_pos + win[(size_t)((qpos + 1) % 4) * S + 4 * t + 1];
-                    v.z = (qpos + 2) * a.cns_pos + win[(size_t)((qpos + 2) % 4) * S + 4 * t + 2];
-                    v.w = (qpos + 3) * a.cns_pos + win[(size_t)((qpos + 3) % 4) * S + 4 * t + 3];
-                    reinterpret_cast<int4 *>(adj)[j] = v;
+                    const uint32_t l0 = win[(size_t)((qpos + 0) & 3) * S + 4 * t + 0];
+                    const uint32_t l1 = win[(size_t)((qpos + 1) & 3) * S + 4 * t + 1];
+                    const uint32_t l2 = win[(size_t)((qpos + 2) & 3) * S + 4 * t + 2];
+                    const uint32_t l3 = win[(size_t)((qpos + 3) & 3) * S + 4 * t + 3];
+                    if (ADJ16) {
+                        uint2 v;
+                        v.x = l0 | (l1 << 16); v.y = l2 | (l3 << 16);
+                        reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
+                    } else {
+                        int4 v;
+                        v.x = (qpos + 0) * a.cns_pos + (int)l0; v.y = (qpos + 1) * a.cns_pos + (int)l1;
+                        v.z = (qpos + 2) * a.cns_pos + (int)l2; v.w = (qpos + 3) * a.cns_pos + (int)l3;
+                        reinterpret_cast<int4 *>(a.vn_adj)[j] = v;
+                    }
                 } else {
-                    for (int i = 0; i < dv; i++)
-                        adj[(size_t)j * dv + i] = (qpos + i) * a.cns_pos + win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                    for (int i = 0; i < dv; i++) {
+                        const uint32_t l = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                        if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l;
+                        else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l;
+                    }
                 }
             }
         }
+        STAMP(5);                                   // emit
         // (the ring slot the next position overwrites is rewritten only after three more barriers)
     }
 
@@ -199,32 +230,34 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
         }
         chan[w] = word;
     }
+    STAMP(6);                                       // channel
+    STAMP_FLUSH();
 }
 
-}  // namespace
-
-extern "C" int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
-                                           int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
-                                           int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream)
+template <bool ADJ16>
+int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials, double eps,
+           int32_t ndoped, const int32_t *doped_positions, void *d_adj, uint32_t *d_chan_bits, void *stream,
+           const char *who)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_vn_adj || !d_chan_bits)))
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sample_philox_device: null buffer or negative ntrials");
+    if (ntrials < 0 || (ntrials > 0 && (!d_adj || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
     if (ndoped < 0 || ndoped > kMaxDoped || (ndoped > 0 && !doped_positions))
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sample_philox_device: 0 <= ndoped <= %d", kMaxDoped);
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: 0 <= ndoped <= %d", who, kMaxDoped);
     if (!(eps >= 0.0 && eps <= 1.0))
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sample_philox_device: eps=%g outside [0,1]", eps);
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: eps=%g outside [0,1]", who, eps);
     if (ntrials == 0) return SCLDPC_OK;
 
     SArgs a{};
     a.dv = p->dv; a.dc = p->dc; a.L = p->L; a.cns_pos = p->cns_pos; a.vns_pos = p->vns_pos;
     a.n = scldpc::n_of(p); a.S = p->cns_pos * p->dc; a.D = p->L + p->dv - 1; a.nw = scldpc::nw_of(p);
     if (a.S > 8192 || p->dv > 8)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                 "scldpc_sample_philox_device: %d sockets per position > 8192 (LDS-resident ranking)", a.S);
-    int lg = 9;                                     // nb = power of two >= max(S, kThreads)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %d sockets per position > 8192 (LDS-resident ranking)", who, a.S);
+    if (ADJ16 && p->cns_pos > 65536)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: position-local CN ids need cns_pos <= 65536", who);
+    int lg = 10;                                    // nb = power of two >= max(S, kThreads)
     while ((1 << lg) < a.S) lg++;
-    a.nb = 1 << lg; a.shift = 32 - lg; a.lgchunk = lg - 3;
+    a.nb = 1 << lg; a.shift = 32 - lg; a.lgchunk = lg - 4;            // 16 waves
     a.dc_shift = -1;
     for (int k = 0; k < 8; k++) if ((1 << k) == p->dc) a.dc_shift = k;
     a.ndoped = ndoped;
@@ -242,22 +275,47 @@ extern "C" int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t
         if (c < x) c += 1.0;
         a.thresh = (uint32_t)c;
     }
-    int off = ((a.nb + 1) + 3) & ~3;
+    int off = (a.nb + 3) & ~3;
     a.off_gkey = off; off += (a.S + 3) & ~3;
     a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
     a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
-    a.off_wsum = off; off += 16;
+    a.off_wsum = off; off += 32 + kWaves * kWaves;
     const size_t lds_bytes = 4u * (size_t)off;
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sample_philox_device: needs %zu B of LDS", lds_bytes);
-    a.vn_adj = d_vn_adj; a.chan = d_chan_bits;
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: needs %zu B of LDS", who, lds_bytes);
+    a.vn_adj = ADJ16 ? nullptr : static_cast<int32_t *>(d_adj);
+    a.vn_adj16 = ADJ16 ? static_cast<uint16_t *>(d_adj) : nullptr;
+    a.chan = d_chan_bits;
 
-    const int kmax = ((a.S + 3) / 4 + kThreads - 1) / kThreads;     // 1..4
-    void (*kern)(const SArgs) = kmax <= 1 ? sample_philox_kernel<1> : kmax == 2 ? sample_philox_kernel<2>
-                                                                                 : sample_philox_kernel<4>;
+    const int kmax = ((a.S + 3) / 4 + kThreads - 1) / kThreads;     // 1 or 2
+    const int rows = a.nb / kThreads;                               // 1, 2, 4 or 8 rows of 64 per wave
+    void (*kern)(const SArgs) = nullptr;
+    if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16>
+                                                                                   : sample_philox_kernel<1, 4, ADJ16>;
+    else           kern = sample_philox_kernel<2, 8, ADJ16>;
+    if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16>;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+}  // namespace
+
+extern "C" int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                           int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
+                                           int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream)
+{
+    return launch<false>(p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits, stream,
+                         "scldpc_sample_philox_device");
+}
+
+extern "C" int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                                 int32_t ntrials, double eps, int32_t ndoped,
+                                                 const int32_t *doped_positions, uint16_t *d_vn_adj16,
+                                                 uint32_t *d_chan_bits, void *stream)
+{
+    return launch<true>(p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_chan_bits, stream,
+                        "scldpc_sample_philox_device_adj16");
 }

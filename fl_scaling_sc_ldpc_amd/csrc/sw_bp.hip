@@ -32,13 +32,13 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
 struct Args {
     int dv, L, vns_pos, cns_pos, n, nk, W, max_it, init_it;
     Layout lay;
-    const int32_t *vn_adj;
+    const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     const uint32_t *chan;
     int32_t *counters;
     uint32_t *erased_out;
 };
 
-template <int DV>
+template <int DV, bool A16>
 __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
     const int trial = blockIdx.x;
     const int n = a.n, nk = a.nk, dv = (DV ? DV : a.dv), nw = a.lay.nw, qcap = a.lay.qcap;
     const int V = a.vns_pos, C = a.cns_pos, L = a.L, W = a.W;
-    const int32_t *adj = a.vn_adj + (size_t)trial * n * dv;
+    const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
     const uint32_t *ch = a.chan + (size_t)trial * nw;
 
     for (int c = tid; c < nk; c += kBlock) cn_state[c] = 0;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             const int j = j0 + u * kBlock;
             er[u] = false;
             if (j < n) {
-                load_adj<DV>(adj, dv, j, c[u]);
+                load_adj<DV, A16>(adj, dv, j, j / V, C, c[u]);
                 er[u] = (S[j >> 5] >> (j & 31)) & 1u;
             }
         }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
                 atomicSub(&pos_cnt[j / V], 1);
                 removed++;
                 int32_t cc[8];
-                load_adj<DV>(adj, dv, (int)j, cc);
+                load_adj<DV, A16>(adj, dv, (int)j, (int)j / V, C, cc);
                 for (int i = 0; i < dv; i++) {
                     const uint32_t c2 = (uint32_t)cc[i];
                     const uint32_t o = atomicSub(&cn_state[c2], kCntOne + j);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             x &= x - 1;
             const int va = w * 32 + b, pos = va / V;
             int32_t cc[8];
-            load_adj<DV>(adj, dv, va, cc);
+            load_adj<DV, A16>(adj, dv, va, pos, C, cc);
             bool pair = true;
             uint32_t partner = 0;
             for (int i = 0; i < dv; i++) {
@@ -246,10 +246,9 @@ int make_layout(const scldpc_code_params *p, int W, Layout *lay)
 
 }  // namespace
 
-extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
-                                   const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
-                                   int32_t W, int32_t max_it, int32_t init_it,
-                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+                        const uint32_t *d_chan_bits, int32_t W, int32_t max_it, int32_t init_it,
+                        int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
     if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
@@ -268,11 +267,28 @@ extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
     a.W = W; a.max_it = max_it; a.init_it = init_it ? init_it : max_it;     // BPW:2101-2102
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
 
-    void (*kern)(const Args) = p->dv == 4 ? sw_bp_kernel<4> : sw_bp_kernel<0>;
+    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true> : sw_bp_kernel<4, false>)
+                                          : (adj16 ? sw_bp_kernel<0, true> : sw_bp_kernel<0, false>);
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                                   const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                   int32_t W, int32_t max_it, int32_t init_it,
+                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_sw_bp(p, ntrials, d_vn_adj, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+}
+
+extern "C" int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                         const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                         int32_t W, int32_t max_it, int32_t init_it,
+                                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_sw_bp(p, ntrials, d_vn_adj16, true, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
 }

@@ -82,24 +82,50 @@ class GlibcRun:
 
 def to_device(vn_adj, chan, device="cuda:0"):
     _require_gpu()
-    d_adj = torch.from_numpy(np.ascontiguousarray(vn_adj, dtype=np.int32)).to(device)
+    vn_adj = np.ascontiguousarray(vn_adj)
+    if vn_adj.dtype != np.int16:
+        vn_adj = vn_adj.astype(np.int32, copy=False)
+    d_adj = torch.from_numpy(vn_adj).to(device)
     d_ch = torch.from_numpy(np.ascontiguousarray(chan).view(np.int32)).to(device)
     return d_adj, d_ch
 
 
-def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None):
-    """Throughput-mode sampling on the device (counter-based; see scldpc_sample_philox_device)."""
+def _is_adj16(d_adj):
+    """int16 tensors carry the compact position-local adjacency (uint16 bit patterns)."""
+    return d_adj.dtype == torch.int16
+
+
+def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None, adj16=False):
+    """Throughput-mode sampling on the device (counter-based; see scldpc_sample_philox_device).
+    adj16=True: compact adjacency, int16 tensor [T,n,dv] holding uint16 position-local CN ids."""
     _require_gpu()
     if out is None:
-        d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int32, device=device)
+        d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int16 if adj16 else torch.int32, device=device)
         d_ch = torch.empty((ntrials, p.nw), dtype=torch.int32, device=device)
     else:
         d_adj, d_ch = out
     darr, dptr = _lib.doped_array(doped)
-    check(lib().scldpc_sample_philox_device(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps),
-                                            darr.size, dptr, d_adj.data_ptr(), d_ch.data_ptr(),
-                                            _stream_ptr(d_adj.device)))
+    fn = lib().scldpc_sample_philox_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sample_philox_device
+    check(fn(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size, dptr, d_adj.data_ptr(),
+             d_ch.data_ptr(), _stream_ptr(d_adj.device)))
     return d_adj, d_ch
+
+
+def adj16_to_global(p, adj16):
+    """Host: uint16 position-local ids [.., n, dv] → the int32 global CN ids of the reference's VNdegree."""
+    a = np.ascontiguousarray(adj16).view(np.uint16).astype(np.int32)
+    pos = (np.arange(p.n, dtype=np.int32) // p.vns_pos)[:, None] + np.arange(p.dv, dtype=np.int32)[None, :]
+    return a + pos * p.cns_pos
+
+
+def global_to_adj16(p, adj):
+    """Host: int32 global CN ids → uint16 position-local ids (as int16 bit patterns for torch)."""
+    adj = np.asarray(adj, dtype=np.int32)
+    pos = (np.arange(p.n, dtype=np.int32) // p.vns_pos)[:, None] + np.arange(p.dv, dtype=np.int32)[None, :]
+    loc = adj - pos * p.cns_pos
+    if loc.min() < 0 or loc.max() >= p.cns_pos:
+        raise ValueError("adjacency is not position-structured (edge i of a VN must land in CN position pos+i)")
+    return loc.astype(np.uint16).view(np.int16)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -110,7 +136,7 @@ def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=Fa
     counters int32 [T,8] (+ rows int32 [T,rows_cap,3], erased int32 [T,nw] when asked)."""
     _require_gpu()
     T = d_adj.shape[0]
-    assert d_adj.is_cuda and d_adj.dtype == torch.int32 and d_adj.is_contiguous()
+    assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
     assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
     assert tuple(d_adj.shape[1:]) == (p.n, p.dv) and tuple(d_chan.shape) == (T, p.nw)
     dev = d_adj.device
@@ -118,10 +144,10 @@ def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=Fa
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     rows = torch.zeros((T, rows_cap, 3), dtype=torch.int32, device=dev) if rows_cap > 0 else None
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
-    check(lib().scldpc_full_bp_device(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(max_it),
-                                      1 if is_term else 0, counters.data_ptr(),
-                                      rows.data_ptr() if rows is not None else None, int(rows_cap),
-                                      erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    fn = lib().scldpc_full_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_full_bp_device
+    check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(max_it), 1 if is_term else 0,
+             counters.data_ptr(), rows.data_ptr() if rows is not None else None, int(rows_cap),
+             erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
     return {"counters": counters, "rows": rows, "erased": erased}
 
 
@@ -129,15 +155,15 @@ def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=No
     """decodeBP_SW (square window, BPW:628-912) for a batch resident on the device."""
     _require_gpu()
     T = d_adj.shape[0]
-    assert d_adj.is_cuda and d_adj.dtype == torch.int32 and d_adj.is_contiguous()
+    assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
     assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
     dev = d_adj.device
     if counters is None:
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
-    check(lib().scldpc_sw_bp_device(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it),
-                                    int(init_it), counters.data_ptr(),
-                                    erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    fn = lib().scldpc_sw_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sw_bp_device
+    check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it), int(init_it),
+             counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
     return {"counters": counters, "erased": erased}
 
 

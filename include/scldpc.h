@@ -134,6 +134,23 @@ int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                         int32_t W, int32_t max_it, int32_t init_it,
                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
 
+/* Compact adjacency variants.  d_vn_adj16 is uint16 [ntrials][n][dv]: the CN index LOCAL to its position
+ * (0 .. cns_pos-1).  Edge i of a VN at position pos always lands in CN position pos+i (BPF:1712), so the
+ * global id is (pos+i)*cns_pos + local.  Half the HBM bytes of the int32 table (one 8-byte row per VN at
+ * dv = 4); same results bit for bit.  Requires cns_pos <= 65536. */
+int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                      int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
+                                      uint16_t *d_vn_adj16, uint32_t *d_chan_bits, void *stream);
+int scldpc_full_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                int32_t max_it, int32_t is_term,
+                                int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                                uint32_t *d_erased_bits, void *stream);
+int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                              const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                              int32_t W, int32_t max_it, int32_t init_it,
+                              int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+
 /* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
  * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),
  * where k is the first trial at which frame_err reaches stop_frame_err (all trials if it never does

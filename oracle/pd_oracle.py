@@ -1,0 +1,230 @@
+"""TEST INFRASTRUCTURE — CPU restatement (numpy / plain Python) of the reference's Python peeling path,
+simulators_sc_ldpc/peeling_decoding/{peeling_decoding.py (PD), sc_ldpc.py}.  Array formulation of what the
+reference does with dicts of sets of namedtuples; each function cites the lines it follows.
+
+Parity status: PINNED — tests/test_pd_oracle.py checks it against tests/golden/pd_*.npz, produced by importing
+the real reference (oracle/make_golden_pd.py): inputs (transmissions, erasure mask), the informative entries
+of simulate_sc_ldpc's 13-tuple, and the r1 / plr outputs of simulate_peeling_decoder_ldpc.
+
+Third-party arithmetic on the path: numpy's legacy RandomState (MT19937; `permutation`, `rand`) and CPython's
+`random.choice` — used through the same library calls the reference makes (numpy 2.2 / CPython 3.10 here and on
+the GPU box), plus an explicit restatement of `random.choice`'s `_randbelow` rejection rule for the device twin.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import random as _pyrandom
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling (sc_ldpc.py:22-56, PD:147-195)
+# ------------------------------------------------------------------------------------------------
+def gen_slots(rs, l, r, L, M):
+    """sc_ldpc.gen_slots: D = L+l-1 draws of rs.permutation(l*M); CN of socket = position*num_cns + perm//r
+    (sc_ldpc.py:22-38); VN (i,u) edge d → cn_indices[i+d][d][u] (sc_ldpc.py:37, 48-50).  int64 [L*M, l]."""
+    num_cns = int(l * M / r)
+    D = L + l - 1
+    cn = np.stack([i * num_cns + rs.permutation(l * M).reshape(l, M) // r for i in range(D)])   # [D, l, M]
+    tr = np.empty((L, M, l), dtype=np.int64)
+    for d in range(l):
+        tr[:, :, d] = cn[d:d + L, d, :]
+    return tr.reshape(L * M, l)
+
+
+def gen_erasures(rs, e, l, r, L, M, doping_points=()):
+    """PD:154 (+ doping PD:166-195): mask of the VNs that become `User`s.  Hard doping (list): erased VNs whose
+    chain position int(tr[0]/cns_per_pos) is doped are dropped; soft doping (dict pos→α): the first int(α·M)
+    VNs of the position are forced known."""
+    mask = rs.rand(L * M) <= e
+    if isinstance(doping_points, dict):
+        for pos, alpha in doping_points.items():
+            mask[pos * M: pos * M + int(alpha * M)] = False
+    elif len(doping_points):
+        pos = np.arange(L * M) // M          # int(tr[0]/cns_per_pos) == VN position for this ensemble
+        mask &= ~np.isin(pos, list(doping_points))
+    return mask
+
+
+# ------------------------------------------------------------------------------------------------
+# sweep peeling + error statistics (PD:270-313, 591-701, 1077-1095)
+# ------------------------------------------------------------------------------------------------
+def peel_closure(tr, mask, total_size, sweep_start):
+    """Residual of `for t in range(sweep_start, total_size): sic_round(schedule, t)` (PD:656-657).
+    A CN fires when it is swept holding exactly one VN (PD:273-277) or when a removal leaves it with exactly one VN
+    and its index <= t (PD:305-308) — i.e. any CN < total_size may fire on a TRANSITION to one VN, but a CN below
+    the sweep start that holds one VN from the outset never does; CNs >= total_size never fire.  The closure does
+    not depend on the order.  Returns the boolean array of VNs still in the schedule."""
+    n, l = tr.shape
+    ncn = int(tr.max()) + 1 if n else 0
+    alive = mask.copy()
+    cnt = np.zeros(ncn, dtype=np.int64)
+    idsum = np.zeros(ncn, dtype=np.int64)
+    for d in range(l):
+        np.add.at(cnt, tr[alive, d], 1)
+        np.add.at(idsum, tr[alive, d], np.flatnonzero(alive))
+    stack = [c for c in range(min(total_size, ncn)) if cnt[c] == 1 and c >= sweep_start]
+    while stack:
+        c = stack.pop()
+        if cnt[c] != 1:
+            continue
+        j = int(idsum[c])
+        alive[j] = False
+        for d in range(l):
+            c2 = int(tr[j, d])
+            cnt[c2] -= 1
+            idsum[c2] -= j
+            if cnt[c2] == 1 and c2 < total_size:
+                stack.append(c2)
+    return alive
+
+
+def components(tr, members):
+    """extract_stopping_sets (PD:1077-1095): connected components of the VNs `members` through ALL the CNs
+    they share.  Returns the list of component sizes and, per member, its component id."""
+    idx = np.flatnonzero(members)
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for j in idx:
+        a = find(("c", int(tr[j, 0])))
+        for d in range(1, tr.shape[1]):
+            b = find(("c", int(tr[j, d])))
+            if a != b:
+                parent[b] = a
+    roots = [find(("c", int(tr[j, 0]))) for j in idx]
+    ids = {}
+    comp = np.array([ids.setdefault(r, len(ids)) for r in roots], dtype=np.int64)
+    sizes = np.bincount(comp, minlength=len(ids)) if len(idx) else np.zeros(0, dtype=np.int64)
+    return sizes, comp, idx
+
+
+def sc_ldpc_trial_stats(tr, mask, l, r, L, M, is_terminated, is_bounded, doping_points=()):
+    """One iteration of the `for o in the_range` loop of simulate_sc_ldpc (PD:632-691) from captured inputs.
+    L is the caller's L (before the function widens it, PD:604-607).  Returns a dict of the per-trial integers."""
+    ignored_head = 0 if is_bounded else 20
+    ignored_head_schedule = 0 if is_bounded else 10
+    ignored_tail = 0 if is_terminated else 20
+    Lw = L + ignored_head + ignored_tail
+    cpp = int(l / r * M)
+    num_positions = Lw + l - 1 if is_terminated else Lw
+    total_size = cpp * num_positions
+    nd = len(doping_points)
+    if isinstance(doping_points, dict):
+        gen = (Lw - ignored_head - ignored_tail) * M - sum(int(a * M) for a in doping_points.values())
+    else:
+        gen = (Lw - nd - ignored_head - ignored_tail) * M
+    blocks = Lw - nd - ignored_head - ignored_tail
+    alive = peel_closure(tr, mask, total_size, ignored_head_schedule * cpp)
+    lo, hi = cpp * ignored_head, total_size - cpp * ignored_tail
+    in_range = ((tr >= lo) & (tr < hi)).any(axis=1)                       # PD:661-664
+    lost = alive & in_range & (tr < total_size).all(axis=1)               # PD:665
+    sizes, comp, idx = components(tr, lost)
+    big = sizes[comp] > 2 if len(idx) else np.zeros(0, dtype=bool)
+    birthday_pos = (tr[idx, 0] // cpp)                                    # int(u.birthday / cns_per_pos), PD:160,687
+    return dict(num_lost=int(lost.sum()), num_lost_exp=int(sizes[sizes > 2].sum()),
+                frame_err=int(lost.any()), frame_err_exp=int((sizes > 2).any()),
+                blocks_failed_exp=int(len(np.unique(birthday_pos[big]))), generated=gen, blocks=blocks,
+                sset_sizes=np.sort(sizes))
+
+
+def simulate_sc_ldpc(seed, e, l, r, L, M, is_terminated, is_bounded, num_repeats=1, max_fuckups=2000,
+                     doping_points=()):
+    """simulate_sc_ldpc (PD:591-701) after `np.random.seed(seed)`: the informative entries of its 13-tuple, in the
+    order (FER, FER_exp, PLR, PLR_exp, #FER_exp, #trials, #lost_exp, #generated, #blocks_failed_exp, #blocks, BLER_exp)."""
+    rs = np.random.RandomState(seed)
+    Lw = L + (0 if is_bounded else 20) + (0 if is_terminated else 20)
+    fu = fu_exp = failed = failed_exp = gen = blk_failed = blk = 0
+    for o in range(num_repeats):
+        tr = gen_slots(rs, l, r, Lw, M)
+        mask = gen_erasures(rs, e, l, r, Lw, M, doping_points)
+        s = sc_ldpc_trial_stats(tr, mask, l, r, L, M, is_terminated, is_bounded, doping_points)
+        fu += s["frame_err"]; fu_exp += s["frame_err_exp"]; failed += s["num_lost"]; failed_exp += s["num_lost_exp"]
+        gen += s["generated"]; blk_failed += s["blocks_failed_exp"]; blk += s["blocks"]
+        if fu >= max_fuckups:
+            break
+    T = o + 1
+    return (fu / T, fu_exp / T, failed / gen, failed_exp / gen, fu_exp, T, failed_exp, gen, blk_failed, blk,
+            blk_failed / blk)
+
+
+# ------------------------------------------------------------------------------------------------
+# random-pick peeling with the degree-1 trajectory (PD:705-789, 1022-1026)
+# ------------------------------------------------------------------------------------------------
+def randbelow(rng, n):
+    """CPython 3.10 Random._randbelow_with_getrandbits, what random.choice(seq) draws (PD:1026)."""
+    k = n.bit_length()
+    x = rng.getrandbits(k)
+    while x >= n:
+        x = rng.getrandbits(k)
+    return x
+
+
+def random_pick_trial(tr, mask, l, r, L, M, e, is_terminated, rng, num_doping_points=0):
+    """One trial of simulate_peeling_decoder_ldpc (PD:740-785) from captured inputs; rng = the Python `random`
+    stream.  Returns (r1 int64 [num_pd_steps+1], plr)."""
+    cpp = int(l / r * M)
+    num_positions = L + l - 1 if is_terminated else L
+    total_size = cpp * num_positions
+    num_pd_steps = int(M * num_positions * (e + 0.1))                    # PD:721
+    n = tr.shape[0]
+    ncn = int(tr.max()) + 1
+    deg = np.zeros(ncn, dtype=np.int64)
+    idsum = np.zeros(ncn, dtype=np.int64)
+    alive = mask.copy()
+    for d in range(l):
+        np.add.at(deg, tr[alive, d], 1)
+        np.add.at(idsum, tr[alive, d], np.flatnonzero(alive))
+    total_generated = (L - num_doping_points) * M                         # PD:747
+    total_recovered = total_generated - int(mask.sum())                   # PD:753 (uid of the last user + 1 = #erased)
+    rdeg = deg[:total_size].copy()                                        # PD:756-757: only CNs < total_size are pickable
+    r1 = np.zeros(num_pd_steps + 1, dtype=np.int64)
+    r1[0] = np.count_nonzero(rdeg == 1)
+    for s in range(num_pd_steps):
+        ones = np.flatnonzero(rdeg == 1)                                  # ascending order (PD:1023)
+        if len(ones) == 0:
+            r1[s + 1] = r1[s]
+            continue
+        m = int(ones[randbelow(rng, len(ones))])
+        j = int(idsum[m])
+        total_recovered += 1
+        for d in range(l):
+            c = int(tr[j, d])
+            idsum[c] -= j
+            deg[c] -= 1
+            if c < total_size:
+                rdeg[c] -= 1
+        r1[s + 1] = np.count_nonzero(rdeg == 1)
+    return r1, (total_generated - total_recovered) / total_generated
+
+
+def simulate_peeling_decoder_ldpc(seed, e, l, r, L, M, is_terminated, num_repeats=1, doping_points=()):
+    """simulate_peeling_decoder_ldpc (PD:705-789) after `np.random.seed(seed); random.seed(seed)`."""
+    rs = np.random.RandomState(seed)
+    rng = _pyrandom.Random(seed)
+    r1s, plrs = [], []
+    for _ in range(num_repeats):
+        tr = gen_slots(rs, l, r, L, M)
+        mask = gen_erasures(rs, e, l, r, L, M, doping_points)
+        r1, plr = random_pick_trial(tr, mask, l, r, L, M, e, is_terminated, rng, len(doping_points))
+        r1s.append(r1); plrs.append(plr)
+    return np.stack(r1s), np.array(plrs)
+
+
+# ------------------------------------------------------------------------------------------------
+# variance reduction (fl_scaling/est_scaling_params.py:42-49, 90-94; driver PD:1264-1294)
+# ------------------------------------------------------------------------------------------------
+def calc_nu_chunk(r1s, r1s_theory, M):
+    """find_level + calc_nu_chunk: crop to the support of the theory curve (theory > 0), d = r1/M − theory/M,
+    steps with r1 == 0 masked, ssquares = nansum(d², axis 0), counts = #unmasked."""
+    last = int(np.max(np.where(r1s_theory > 0))) + 1                      # est_scaling_params.py:91
+    th = r1s_theory[r1s_theory > 0]                                       # :92 (a prefix for a real theory curve)
+    x = (r1s[:, :last][:, :r1s_theory.shape[0]] / M)                      # :93, :132-133
+    d = x - th / M
+    d[x == 0] = np.nan                                                    # :135
+    return np.nansum(d ** 2, axis=0), np.sum(~np.isnan(d), axis=0)        # :136-137

@@ -240,3 +240,27 @@ def test_accumulate_run_ordered_stop(E):
             E.accumulate_run(d, run, stop)
             ref = np.zeros(E.NRUN, dtype=np.int64); ref[1] = 2
             assert run.cpu().tolist() == numpy_accumulate(cnt, ref, stop).tolist(), (T, stop)
+
+
+@pytest.mark.parametrize("L,N,eps", [(50, 1000, 0.48), (16, 200, 0.44), (9, 24, 0.5), (12, 2000, 0.46)])
+def test_compact_adjacency_is_equivalent(E, L, N, eps):
+    """uint16 position-local adjacency: same codes, same decoder outputs as the int32 table, bit for bit."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 12
+    a32, c32 = E.sample_philox(p, 11, 500, T, eps, doped=(2,))
+    a16, c16 = E.sample_philox(p, 11, 500, T, eps, doped=(2,), adj16=True)
+    torch.cuda.synchronize()
+    assert (c32 == c16).all()
+    assert (E.adj16_to_global(p, a16.cpu().numpy()) == a32.cpu().numpy()).all()
+    assert (E.global_to_adj16(p, a32.cpu().numpy()[0]) == a16.cpu().numpy()[0]).all()
+    for kw in (dict(), dict(max_it=4), dict(is_term=False), dict(rows_cap=1024)):
+        o32 = E.full_bp(p, a32, c32, want_erased=True, **kw)
+        o16 = E.full_bp(p, a16, c16, want_erased=True, **kw)
+        assert (o32["counters"] == o16["counters"]).all() and (o32["erased"] == o16["erased"]).all(), kw
+        if kw.get("rows_cap"):
+            assert (o32["rows"] == o16["rows"]).all()
+    if p.nk * 4 < 150_000:
+        s32 = E.sw_bp(p, a32, c32, 5, 4, 9, want_erased=True)
+        s16 = E.sw_bp(p, a16, c16, 5, 4, 9, want_erased=True)
+        assert (s32["counters"] == s16["counters"]).all() and (s32["erased"] == s16["erased"]).all()

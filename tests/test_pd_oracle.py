@@ -1,0 +1,80 @@
+"""oracle/pd_oracle.py (numpy restatement of the reference's Python peeling path) against the golden vectors
+produced by importing the REAL reference (oracle/make_golden_pd.py → tests/golden/pd_*.npz)."""
+import glob
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+ER = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_er_*.npz")))
+TR = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_tr_*.npz")))
+
+
+def _load(path):
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    doping = m["doping"]
+    if m.get("doping_soft"):
+        doping = {int(k): v for k, v in doping.items()}
+    return z, m, doping
+
+
+@pytest.mark.parametrize("path", ER, ids=[os.path.basename(p)[:-4] for p in ER])
+def test_simulate_sc_ldpc_tuple(path):
+    from oracle import pd_oracle as P
+    z, m, doping = _load(path)
+    seeds = z["seed"] if m["M"] <= 200 else z["seed"][:3]
+    for k, s in enumerate(seeds):
+        got = P.simulate_sc_ldpc(int(s), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], m["is_bounded"],
+                                 1, 2000, doping)
+        assert np.allclose(got, z["tuple11"][k], rtol=0, atol=1e-15), (path, s, got, z["tuple11"][k])
+    if m["M"] <= 200:
+        got = P.simulate_sc_ldpc(int(z["seed"][0]), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"],
+                                 m["is_bounded"], 3, 2000, doping)
+        assert np.allclose(got, z["multi3"], rtol=0, atol=1e-15)
+    if "transmissions" in z.files:                      # the sampled inputs themselves
+        Lw = m["L"] + (0 if m["is_bounded"] else 20) + (0 if m["is_terminated"] else 20)
+        for k in range(min(5, len(seeds))):
+            rs = np.random.RandomState(int(seeds[k]))
+            tr = P.gen_slots(rs, m["l"], m["r"], Lw, m["M"])
+            mask = rs.rand(Lw * m["M"]) <= m["e"]
+            assert (tr == z["transmissions"][k]).all() and (mask == z["mask"][k].astype(bool)).all()
+
+
+@pytest.mark.parametrize("path", TR, ids=[os.path.basename(p)[:-4] for p in TR])
+def test_random_pick_trajectories(path):
+    from oracle import pd_oracle as P
+    z, m, doping = _load(path)
+    seeds = z["seed"] if m["M"] <= 200 else z["seed"][:1]
+    for k, s in enumerate(seeds):
+        r1, plr = P.simulate_peeling_decoder_ldpc(int(s), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"],
+                                                  1, doping)
+        assert (r1[0] == z["r1"][k]).all() and plr[0] == z["plr"][k], (path, s)
+    if m["M"] <= 200:
+        r1, plr = P.simulate_peeling_decoder_ldpc(int(z["seed"][0]), m["e"], m["l"], m["r"], m["L"], m["M"],
+                                                  m["is_terminated"], 2, doping)
+        assert (r1 == z["multi2_r1"]).all() and (plr == z["multi2_plr"]).all()
+
+
+def test_randbelow_is_random_choice():
+    from oracle import pd_oracle as P
+    a, b = random.Random(7), random.Random(7)
+    for n in (1, 2, 3, 5, 17, 255, 256, 1000, 4097, 26500):
+        seq = range(n)
+        assert [a.choice(seq) for _ in range(50)] == [P.randbelow(b, n) for _ in range(50)]
+
+
+def test_calc_nu_chunk_matches_definition():
+    from oracle import pd_oracle as P
+    rng = np.random.RandomState(0)
+    th = np.concatenate([np.linspace(50, 1, 40), np.zeros(10)])
+    r1 = rng.randint(0, 80, size=(7, 60))
+    ss, cnt = P.calc_nu_chunk(r1, th, 100)
+    x = r1[:, :40] / 100.0
+    d = x - th[:40] / 100.0
+    ok = x != 0
+    assert np.allclose(ss, np.where(ok, d ** 2, 0).sum(0)) and (cnt == ok.sum(0)).all()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: where do the sampler and the full-BP kernel spend their cycles?  Uses the stamped build
+(make -C fl_scaling_sc_ldpc_amd/csrc stamps → libscldpc_hip_stamps.so): lane 0 of wave 0 of every workgroup
+sums s_memtime deltas per phase.  Shares, not absolute times, are what to read (stamps cost cycles)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["SCLDPC_LIB_PATH"] = os.path.join(ROOT, "fl_scaling_sc_ldpc_amd", "libscldpc_hip_stamps.so")
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from fl_scaling_sc_ldpc_amd import engine as E
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+adj16 = "--adj32" not in sys.argv
+p = E.make_params(4, 8, 50, 1000)
+L = E.lib()
+L.scldpc_debug_set_stamps.argtypes = [C.c_void_p]
+buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
+assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
+
+
+def show(title, names):
+    torch.cuda.synchronize()
+    s = buf.cpu().numpy().astype(np.float64)
+    tot = s.sum(axis=1)
+    print(f"{title}: mean {tot.mean():.0f} cycles/workgroup  (min {tot.min():.0f}, max {tot.max():.0f})")
+    for k, nm in enumerate(names):
+        print(f"   {nm:28s} {s[:, k].mean():12.0f}  {100 * s[:, k].sum() / tot.sum():5.1f} %")
+    buf.zero_()
+
+
+d_adj, d_ch = E.sample_philox(p, 1, 0, T, 0.48, adj16=adj16)
+show("sample_philox_kernel", ["clear", "keys+histogram", "scan", "group", "rank", "emit", "channel"])
+out = E.full_bp(p, d_adj, d_ch)
+show("full_bp_kernel", ["clear+channel", "build", "release", "wave reductions", "barrier wait", "bookkeeping",
+                        "final+expurgation"])
+it = out["counters"][:, 5].float().mean().item()
+print("mean iterations", it)
