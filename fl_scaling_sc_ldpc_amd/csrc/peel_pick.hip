@@ -1,0 +1,271 @@
+// Random-pick peeling with the degree-1-CN trajectory — gfx950 kernel.
+//
+// Replaces, per trial, the body of the `for o in trange(num_repeats)` loop of simulate_peeling_decoder_ldpc
+// (simulators_sc_ldpc/peeling_decoding/peeling_decoding.py = PD, PD:740-785):
+//   r[t] = #erased VNs on CN t for t < total_size (PD:756-757; CNs beyond a non-terminated chain's L positions stay in
+//   the graph but are never pickable);  r1[0] = #{t : r[t] == 1};  then num_pd_steps times:
+//     m = random.choice(np.flatnonzero(r == 1))   (PD:1022-1026: ascending index order; CPython's _randbelow:
+//         k = n.bit_length(); draw getrandbits(k) = MT19937 word >> (32-k) until < n)
+//     remove the single VN of m from its l CNs, r[s] -= 1 for s < total_size (PD:769-777);  r1[step+1] = #{r == 1}.
+//   With no degree-1 CN left the count is copied forward and no number is drawn (PD:765-767).
+// This is a chain of dependent steps: the parallelism is across trials (one workgroup each, stepped by one wave)
+// and inside a step (rank-select of the x-th set bit of the degree-1 bitmap by popcount + DPP prefix scan; the l
+// CN updates on l lanes).  State per trial in LDS: one [cnt:4 | Σ VN id:24] word per CN, the degree-1 bitmap, and
+// the generator: either the caller's MT19937 state (exact replay of the Python `random` stream; read and written
+// back so that a host loop can chain trials like the reference's single stream) or a per-trial Philox counter.
+#include "common.h"
+#include "kernel_util.h"
+
+namespace {
+
+using namespace scldpc_dev;
+
+constexpr int kBlock = 256;
+
+struct Args {
+    int dv, vns_pos, cns_pos, n, ncn, total_size, steps, nw, nd1;     // nd1 = 64-bit words of the degree-1 bitmap
+    int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
+    uint32_t magic_v, seed_lo, seed_hi;
+    unsigned long long trial0;
+    int off_d1, off_mt, off_u, off_sc;   // LDS offsets (32-bit words) behind the CN words
+    const void *vn_adj;
+    const uint32_t *chan;
+    uint32_t *mt;                   // [T][625]: 624 state words + index
+    int32_t *r1;                    // [T][steps+1] or null
+    int32_t *out;                   // [T][4]: #erased, #picked, last r1, steps executed with a pick
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int DV, bool A16>
+__global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *cn = lds;                                                   // ncn words
+    unsigned long long *d1 = reinterpret_cast<unsigned long long *>(lds + a.off_d1);   // nd1 words of 64 bits
+    uint32_t *mt = lds + a.off_mt;                                        // 624 words
+    uint32_t *U = lds + a.off_u;                                          // channel bits (build only)
+    int *sc = reinterpret_cast<int *>(lds + a.off_sc);                   // [0] #erased, [1] r1[0]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int trial = blockIdx.x;
+    const int n = a.n, dv = (DV ? DV : a.dv), ts = a.total_size;
+    const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
+    auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };
+
+    for (int c = tid; c < a.ncn; c += kBlock) cn[c] = 0;
+    for (int w = tid; w < a.nd1; w += kBlock) d1[w] = 0ull;
+    if (tid == 0) { sc[0] = 0; sc[1] = 0; }
+    int ne_local = 0;
+    for (int w = tid; w < a.nw; w += kBlock) {
+        uint32_t x = a.chan[(size_t)trial * a.nw + w];
+        if (w == a.nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+        U[w] = x;
+        ne_local += __popc(x);
+    }
+    if (a.rng_mode == 0)
+        for (int i = tid; i < 624; i += kBlock) mt[i] = a.mt[(size_t)trial * 625 + i];
+    __syncthreads();
+    {
+        const uint32_t tot = wave_inclusive_scan((uint32_t)ne_local);
+        if (lane == 63 && tot) atomicAdd(&sc[0], (int)tot);
+    }
+    for (int j = tid; j < n; j += kBlock) {
+        if ((U[j >> 5] >> (j & 31)) & 1u) {
+            int32_t cc[8];
+            load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+            for (int i = 0; i < dv; i++) atomicAdd(&cn[cc[i]], kCntOne + (uint32_t)j);
+        }
+    }
+    __syncthreads();
+    // degree-1 bitmap over the pickable CNs (PD:756-757) and r1[0] (PD:758)
+    int n1_local = 0;
+    for (int base = 0; base < ts; base += kBlock) {
+        const int c = base + tid;
+        const bool one = c < ts && (cn[c] >> kCntShift) == 1u;
+        const unsigned long long m = __ballot(one);
+        if (lane == 0 && c < ts) d1[c >> 6] = m;
+        n1_local += one;
+    }
+    {
+        const uint32_t tot = wave_inclusive_scan((uint32_t)n1_local);
+        if (lane == 63 && tot) atomicAdd(&sc[1], (int)tot);
+    }
+    __syncthreads();
+    if (wave != 0) return;                     // the step chain runs on one wave; no barriers below
+
+    int n1 = sc[1], picked = 0, with_pick = 0;
+    int32_t *r1 = a.r1 ? a.r1 + (size_t)trial * (a.steps + 1) : nullptr;
+    if (r1 && lane == 0) r1[0] = n1;
+    uint32_t mti = a.rng_mode == 0 ? a.mt[(size_t)trial * 625 + 624] : 0u;      // MT index, or Philox draw counter
+    const unsigned long long gtrial = a.trial0 + (unsigned long long)trial;
+    const int wpl = (a.nd1 + 63) / 64;         // bitmap words per lane for the rank-select
+
+    auto next_u32 = [&]() -> uint32_t {        // wave-uniform result
+        if (a.rng_mode == 0) {
+            if (mti >= 624u) {                 // twist, in lockstep batches of 64 == the sequential recurrence
+                for (int b = 0; b < 624; b += 64) {
+                    const int i = b + lane;
+                    uint32_t y = 0, src = 0;
+                    if (i < 624) {
+                        const uint32_t cur = mt[i], nxt = mt[i == 623 ? 0 : i + 1];
+                        src = mt[i < 227 ? i + 397 : i - 227];
+                        y = (cur & 0x80000000u) | (nxt & 0x7FFFFFFFu);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < 624) mt[i] = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                mti = 0;
+            }
+            uint32_t y = mt[mti++];
+            y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+            return y;
+        }
+        uint32_t r[4];
+        philox4x32_10(mti >> 2, 0x90000000u, (uint32_t)gtrial, (uint32_t)(gtrial >> 32), a.seed_lo, a.seed_hi, r);
+        const uint32_t y = r[mti & 3u];
+        mti++;
+        return y;
+    };
+
+    int s = 0;
+    for (; s < a.steps && n1 > 0; s++) {
+        // ---- x = _randbelow(n1) ----------------------------------------------------------------
+        const int k = 32 - __clz(n1);
+        uint32_t x;
+        do { x = next_u32() >> (32 - k); } while (x >= (uint32_t)n1);
+        // ---- m = x-th set bit of the degree-1 bitmap, ascending ---------------------------------
+        uint32_t cl = 0;
+        for (int w = 0; w < wpl; w++) {
+            const int idx = lane * wpl + w;
+            cl += idx < a.nd1 ? (uint32_t)__popcll(d1[idx]) : 0u;
+        }
+        const uint32_t incl = wave_inclusive_scan(cl);
+        const unsigned long long hit = __ballot(incl > x);
+        const int L0 = __ffsll((long long)hit) - 1;
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cl), L0);
+        int m = -1;
+        if (lane == L0) {
+            uint32_t r = x - before;
+            for (int w = 0; w < wpl; w++) {
+                unsigned long long word = d1[lane * wpl + w];
+                const uint32_t pc = (uint32_t)__popcll(word);
+                if (r < pc) {
+                    while (r--) word &= word - 1;
+                    m = (lane * wpl + w) * 64 + (__ffsll((long long)word) - 1);
+                    break;
+                }
+                r -= pc;
+            }
+        }
+        m = __builtin_amdgcn_readlane(m, L0);
+        // ---- remove its single VN from all its CNs (PD:769-777) ------------------------------------
+        const int j = (int)(cn[m] & kSumMask);
+        int32_t cc[8];
+        load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+        bool plus = false, minus = false;
+        if (lane < dv) {
+            const int c = cc[lane];
+            const uint32_t w = cn[c] - (kCntOne + (uint32_t)j);
+            cn[c] = w;
+            const uint32_t nc = w >> kCntShift;
+            if (c < ts) {
+                minus = nc == 0u;                       // was 1
+                plus = nc == 1u;                        // became 1
+                if (plus || minus) atomicXor(&d1[c >> 6], 1ull << (c & 63));
+            }
+        }
+        n1 += __popcll(__ballot(plus)) - __popcll(__ballot(minus));
+        picked++; with_pick++;
+        if (r1 && lane == 0) r1[s + 1] = n1;
+    }
+    // no degree-1 CN left: the count (0) is copied forward, nothing is drawn (PD:765-767)
+    if (r1)
+        for (int t = s + 1 + lane; t <= a.steps; t += 64) r1[t] = n1;
+    if (a.rng_mode == 0) {
+        for (int i = lane; i < 624; i += 64) a.mt[(size_t)trial * 625 + i] = mt[i];
+        if (lane == 0) a.mt[(size_t)trial * 625 + 624] = mti;
+    }
+    if (lane == 0) {
+        int32_t *o = a.out + (size_t)trial * 4;
+        o[0] = sc[0]; o[1] = picked; o[2] = n1; o[3] = with_pick;
+    }
+}
+
+}  // namespace
+
+static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+                            const uint32_t *d_chan_bits, int32_t total_size, int32_t num_steps,
+                            uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
+                            int32_t *d_r1, int32_t *d_out, void *stream)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_pick_device: null buffer or negative ntrials");
+    const int n = scldpc::n_of(p), ncn = scldpc::nk_of(p);
+    if (total_size < 0 || total_size > ncn || num_steps < 0)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_pick_device: total_size outside [0,%d] or negative steps", ncn);
+    if (ntrials == 0) return SCLDPC_OK;
+    if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
+    Args a{};
+    a.dv = p->dv; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.ncn = ncn; a.total_size = total_size;
+    a.steps = num_steps; a.nw = (n + 31) / 32; a.nd1 = (total_size + 63) / 64 + 1;
+    a.rng_mode = d_mt_state ? 0 : 1;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.trial0 = trial0;
+    a.magic_v = (uint32_t)((1ull << 32) / (uint32_t)p->vns_pos) + 1u;
+    for (int64_t q = 0; q <= p->L; q++) {
+        const uint64_t x0 = (uint64_t)q * p->vns_pos, x1 = x0 ? x0 - 1 : 0;
+        if (((x0 * a.magic_v) >> 32) != (uint64_t)q || ((x1 * a.magic_v) >> 32) != x1 / (uint64_t)p->vns_pos)
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: reciprocal division inexact");
+    }
+    int off = (ncn + 3) & ~3;
+    a.off_d1 = off; off += (2 * a.nd1 + 3) & ~3;
+    a.off_mt = off; off += 624;
+    a.off_u = off;  off += (a.nw + 3) & ~3;
+    a.off_sc = off; off += 4;
+    const size_t lds_bytes = 4u * (size_t)off;
+    if (lds_bytes + 64 > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                 "scldpc_peel_pick_device: %d CN words + bitmaps do not fit 160 KiB of LDS", ncn);
+    a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.mt = d_mt_state; a.r1 = d_r1; a.out = d_out;
+    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true> : peel_pick_kernel<4, false>)
+                                          : (adj16 ? peel_pick_kernel<0, true> : peel_pick_kernel<0, false>);
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntrials,
+                                       const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                       int32_t total_size, int32_t num_steps,
+                                       uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
+                                       int32_t *d_r1, int32_t *d_out, void *stream)
+{
+    return launch_peel_pick(p, ntrials, d_vn_adj, false, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
+                            d_r1, d_out, stream);
+}
+
+extern "C" int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                             const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                             int32_t total_size, int32_t num_steps,
+                                             uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
+                                             int32_t *d_r1, int32_t *d_out, void *stream)
+{
+    return launch_peel_pick(p, ntrials, d_vn_adj16, true, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
+                            d_r1, d_out, stream);
+}

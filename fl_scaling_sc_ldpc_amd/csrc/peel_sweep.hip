@@ -1,0 +1,322 @@
+// Sweep peeling + stopping-set statistics of the reference's Python error-rate simulator — gfx950 kernel.
+//
+// Replaces, per trial, the body of the `for o in the_range` loop of simulate_sc_ldpc
+// (simulators_sc_ldpc/peeling_decoding/peeling_decoding.py = PD, PD:632-691):
+//   * `for t in range(start, total_size): sic_round(schedule, t)`  (PD:656-657, sic_round PD:270-287,
+//     subtract_interference PD:294-313).  Its residual does not depend on the sweep order: it is the closure of
+//     "a CN holding exactly one VN releases it", where a CN index < total_size may fire on any TRANSITION to one VN
+//     (PD:305-308), a CN >= sweep_start also when it holds one VN from the outset (PD:273-277), and CNs >= total_size
+//     never (the truncated tail of a non-terminated chain).  → the same frontier machine as full_bp.hip, with the
+//     first round restricted to CNs >= sweep_start.
+//   * `lost` = VNs still attached to a CN of [lost_lo, lost_hi) whose CNs are all < total_size (PD:659-666);
+//   * extract_stopping_sets (PD:1077-1095) = connected components of `lost` through all shared CNs; "expurgated"
+//     statistics ignore components of <= 2 VNs (PD:677-691): #lost_exp, and the number of distinct chain positions
+//     int(birthday / cns_per_pos) among the VNs of larger components.
+// Components are found by a lock-free union–find over the CNs (every lost VN unites its dv CNs), reusing the LDS
+// words of the CN state once peeling is done: [size saturating at 3 : 2 | parent : 30].
+#include "common.h"
+#include "kernel_util.h"
+
+namespace {
+
+using namespace scldpc_dev;
+
+constexpr int kBlock = 1024;
+enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_NE = 9, S_LOST = 10, S_LOST_EXP = 11, S_NSCAL = 16 };
+
+struct Layout { int cn_state, U, fbits, frozen, q0, q1, pos_flag, scal, total, qcap, nw; };
+
+struct Args {
+    int dv, L, vns_pos, cns_pos, n, ncn, total_size, sweep_start, lost_lo, lost_hi;
+    uint32_t magic_v;
+    Layout lay;
+    const void *vn_adj;
+    const uint32_t *chan;
+    int32_t *out;               // [T][8]: lost, lost_exp, blocks_failed_exp, 0, 0, rounds, 0, #erased
+    uint32_t *lost_out;         // optional [T][nw]
+};
+
+constexpr uint32_t kParentMask = 0x3FFFFFFFu;
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t *p, uint32_t x)
+{
+    for (;;) {
+        const uint32_t px = p[x] & kParentMask;
+        if (px == x) return x;
+        const uint32_t gp = p[px] & kParentMask;
+        if (gp != px) atomicCAS(&p[x], px, gp);        // path halving; only ever replaces a parent by an ancestor
+        x = px;
+    }
+}
+
+__device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(p, a); b = uf_find(p, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }          // hook the larger root under the smaller
+        if (atomicCAS(&p[a], a, b) == a) return;
+    }
+}
+
+template <int DV, bool A16>
+__global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *cn_state = lds + a.lay.cn_state;
+    uint32_t *U = lds + a.lay.U;
+    uint32_t *fbits = lds + a.lay.fbits;
+    uint32_t *frozen = lds + a.lay.frozen;
+    uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
+    int *pos_flag = reinterpret_cast<int *>(lds + a.lay.pos_flag);
+    int *scal = reinterpret_cast<int *>(lds + a.lay.scal);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int trial = blockIdx.x;
+    const int n = a.n, ncn = a.ncn, dv = (DV ? DV : a.dv), cn_lim = a.total_size, nw = a.lay.nw, qcap = a.lay.qcap;
+    const int V = a.vns_pos;
+    const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
+    const uint32_t *ch = a.chan + (size_t)trial * nw;
+    auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };
+
+    for (int c = tid; c < ncn; c += kBlock) cn_state[c] = 0;
+    int ne_local = 0;
+    for (int w = tid; w < nw; w += kBlock) {
+        uint32_t x = ch[w];
+        if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+        U[w] = x;
+        ne_local += __popc(x);
+    }
+    if (tid < S_NSCAL) scal[tid] = 0;
+    for (int i = tid; i < a.L; i += kBlock) pos_flag[i] = 0;
+    __syncthreads();
+    {
+        const uint32_t tot = wave_inclusive_scan((uint32_t)ne_local);
+        if (lane == 63 && tot) atomicAdd(&scal[S_NE], (int)tot);
+    }
+    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+        int32_t c[4][8];
+        bool er[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * kBlock;
+            er[u] = false;
+            if (j < n) {
+                load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, c[u]);
+                er[u] = (U[j >> 5] >> (j & 31)) & 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * kBlock;
+            if (j < n && er[u])
+                for (int i = 0; i < dv; i++) atomicAdd(&cn_state[c[u][i]], kCntOne + (uint32_t)j);
+        }
+    }
+    __syncthreads();
+
+    // ---- peeling to the fixpoint (rounds as in full_bp.hip; the order is irrelevant for the residual) ----
+    int iter = 0, ncur = 0;
+    bool scan = true;
+    for (;;) {
+        const int g = iter % 3, gn = (iter + 1) % 3;
+        uint32_t *qc = q[iter & 1], *qn = q[(iter + 1) & 1];
+        if (tid == 0) { scal[S_PUSH + gn] = 0; scal[S_OVF + gn] = 0; scal[S_REM + gn] = 0; }
+        int removed = 0;
+        auto release = [&](int c) {
+            const uint32_t w = cn_state[c];
+            if ((w >> kCntShift) != 1u) return;
+            const int j = (int)(w & kSumMask);
+            int32_t cc[8];
+            load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+            const uint32_t bit = 1u << (j & 31);
+            if (!(atomicAnd(&U[j >> 5], ~bit) & bit)) return;
+            removed++;
+            for (int i = 0; i < dv; i++) {
+                const uint32_t o = atomicSub(&cn_state[cc[i]], kCntOne + (uint32_t)j) >> kCntShift;
+                if (o == 2u && cc[i] < cn_lim) {                    // transition to one VN: may fire (PD:305-308)
+                    const int idx = atomicAdd(&scal[S_PUSH + g], 1);
+                    if (idx < qcap) qn[idx] = (uint32_t)cc[i]; else scal[S_OVF + g] = 1;
+                }
+            }
+        };
+        if (scan) {
+            // Round 0: only swept CNs may fire from the outset (PD:656, 273-277); CNs below the sweep start that
+            // hold one VN at the outset are remembered in `frozen` and never fire.  A later re-scan (queue
+            // overflow) takes every other CN < total_size holding one VN: those got there by a transition.
+            for (int base = 0; base < cn_lim; base += kBlock) {
+                const int c = base + tid;
+                const bool one = c < cn_lim && (cn_state[c] >> kCntShift) == 1u;
+                bool v, fz;
+                if (iter == 0) { v = one && c >= a.sweep_start; fz = one && c < a.sweep_start; }
+                else           { fz = c < cn_lim && ((frozen[c >> 5] >> (c & 31)) & 1u); v = one && !fz; }
+                const unsigned long long m = __ballot(v), mf = __ballot(fz);
+                if (c - lane < cn_lim) {
+                    if (lane == 0) { fbits[c >> 5] = (uint32_t)m; frozen[c >> 5] = (uint32_t)mf; }
+                    if (lane == 32) { fbits[c >> 5] = (uint32_t)(m >> 32); frozen[c >> 5] = (uint32_t)(mf >> 32); }
+                }
+            }
+            __syncthreads();
+            for (int base = 0; base < cn_lim; base += kBlock) {
+                const int c = base + tid;
+                if (c < cn_lim && ((fbits[c >> 5] >> (c & 31)) & 1u)) release(c);
+            }
+        } else {
+            for (int k = tid; k < ncur; k += kBlock) release((int)qc[k]);
+        }
+        {
+            const uint32_t tot = wave_inclusive_scan((uint32_t)removed);
+            if (lane == 63 && tot) atomicAdd(&scal[S_REM + g], (int)tot);
+        }
+        __syncthreads();
+        const int rem = scal[S_REM + g];
+        const bool ovf = scal[S_OVF + g] != 0;
+        ncur = ovf ? 0 : scal[S_PUSH + g];
+        iter++;
+        if (ovf) { scan = true; continue; }
+        scan = false;
+        if (ncur == 0 && rem >= 0) break;                           // nothing queued: fixpoint
+    }
+    __syncthreads();
+
+    // ---- lost set, components, expurgated statistics -----------------------------------------
+    auto is_lost = [&](int j, int32_t (&cc)[8]) {
+        load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+        bool in_range = false, all_inside = true;
+        for (int i = 0; i < dv; i++) {
+            in_range |= cc[i] >= a.lost_lo && cc[i] < a.lost_hi;    // PD:661-664
+            all_inside &= cc[i] < cn_lim;                           // PD:665
+        }
+        return in_range && all_inside;
+    };
+    for (int c = tid; c < ncn; c += kBlock) cn_state[c] = (uint32_t)c;       // every CN its own root, size 0
+    __syncthreads();
+    for (int w = tid; w < nw; w += kBlock) {
+        uint32_t x = U[w], keep = 0;
+        while (x) {
+            const int b = __ffs((int)x) - 1;
+            x &= x - 1;
+            int32_t cc[8];
+            if (is_lost(w * 32 + b, cc)) {
+                keep |= 1u << b;
+                for (int i = 1; i < dv; i++) uf_unite(cn_state, (uint32_t)cc[0], (uint32_t)cc[i]);
+            }
+        }
+        U[w] = keep;                                                // U := lost
+    }
+    __syncthreads();
+    for (int w = tid; w < nw; w += kBlock) {                       // component sizes, saturating at 3
+        uint32_t x = U[w];
+        while (x) {
+            const int b = __ffs((int)x) - 1;
+            x &= x - 1;
+            int32_t cc[8];
+            load_adj<DV, A16>(adj, dv, w * 32 + b, pos_of(w * 32 + b), a.cns_pos, cc);
+            const uint32_t r = uf_find(cn_state, (uint32_t)cc[0]);
+            for (;;) {
+                const uint32_t old = cn_state[r];
+                if ((old >> 30) == 3u || atomicCAS(&cn_state[r], old, old + (1u << 30)) == old) break;
+            }
+        }
+    }
+    __syncthreads();
+    int lost = 0, lost_exp = 0;
+    for (int w = tid; w < nw; w += kBlock) {
+        uint32_t x = U[w];
+        while (x) {
+            const int b = __ffs((int)x) - 1;
+            x &= x - 1;
+            const int j = w * 32 + b;
+            int32_t cc[8];
+            load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+            lost++;
+            if ((cn_state[uf_find(cn_state, (uint32_t)cc[0])] >> 30) == 3u) {      // component of > 2 VNs
+                lost_exp++;
+                pos_flag[cc[0] / a.cns_pos] = 1;                    // int(u.birthday / cns_per_pos), PD:160,687
+            }
+        }
+    }
+    {
+        const uint32_t t1 = wave_inclusive_scan((uint32_t)lost), t2 = wave_inclusive_scan((uint32_t)lost_exp);
+        if (lane == 63 && t1) atomicAdd(&scal[S_LOST], (int)t1);
+        if (lane == 63 && t2) atomicAdd(&scal[S_LOST_EXP], (int)t2);
+    }
+    __syncthreads();
+    if (a.lost_out)
+        for (int w = tid; w < nw; w += kBlock) a.lost_out[(size_t)trial * nw + w] = U[w];
+    if (tid == 0) {
+        int blocks = 0;
+        for (int pos = 0; pos < a.L; pos++) blocks += pos_flag[pos];
+        int32_t *o = a.out + (size_t)trial * 8;
+        o[0] = scal[S_LOST]; o[1] = scal[S_LOST_EXP]; o[2] = blocks; o[3] = 0; o[4] = 0; o[5] = iter; o[6] = 0;
+        o[7] = scal[S_NE];
+    }
+}
+
+}  // namespace
+
+static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+                             const uint32_t *d_chan_bits, int32_t total_size, int32_t sweep_start,
+                             int32_t lost_lo, int32_t lost_hi, int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_sweep_device: null buffer or negative ntrials");
+    const int n = scldpc::n_of(p), ncn = scldpc::nk_of(p);
+    if (total_size < 0 || total_size > ncn || sweep_start < 0 || lost_lo < 0 || lost_hi > ncn)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_sweep_device: CN ranges outside [0,%d]", ncn);
+    if (ntrials == 0) return SCLDPC_OK;
+    if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
+    Args a{};
+    int off = 0;
+    auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
+    a.lay.nw = (n + 31) / 32;
+    a.lay.cn_state = take(ncn);
+    a.lay.U = take(a.lay.nw);
+    a.lay.fbits = take(((ncn + 63) / 64) * 2);
+    a.lay.frozen = take(((ncn + 63) / 64) * 2);
+    a.lay.pos_flag = take(p->L + p->dv);
+    a.lay.scal = take(S_NSCAL);
+    int qcap = ((scldpc::kMaxLdsBytes / 4 - off) / 2) & ~3;
+    if (qcap > 8192) qcap = 8192;
+    if (qcap < 256)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                 "scldpc_peel_sweep_device: %d CN words + %d VN bits do not fit 160 KiB of LDS", ncn, n);
+    a.lay.qcap = qcap; a.lay.q0 = take(qcap); a.lay.q1 = take(qcap); a.lay.total = off;
+    a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.ncn = ncn;
+    a.total_size = total_size; a.sweep_start = sweep_start; a.lost_lo = lost_lo; a.lost_hi = lost_hi;
+    a.magic_v = (uint32_t)((1ull << 32) / (uint32_t)p->vns_pos) + 1u;
+    for (int64_t q = 0; q <= p->L; q++) {                           // exactness of the reciprocal on [0, n)
+        const uint64_t x0 = (uint64_t)q * p->vns_pos, x1 = x0 ? x0 - 1 : 0;
+        if (((x0 * a.magic_v) >> 32) != (uint64_t)q || ((x1 * a.magic_v) >> 32) != x1 / (uint64_t)p->vns_pos)
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: reciprocal division inexact");
+    }
+    a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.out = d_out; a.lost_out = d_lost_bits;
+    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true> : peel_sweep_kernel<4, false>)
+                                          : (adj16 ? peel_sweep_kernel<0, true> : peel_sweep_kernel<0, false>);
+    const size_t lds_bytes = 4u * (size_t)a.lay.total;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_peel_sweep_device(const scldpc_code_params *p, int32_t ntrials,
+                                        const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                        int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
+                                        int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+{
+    return launch_peel_sweep(p, ntrials, d_vn_adj, false, d_chan_bits, total_size, sweep_start, lost_lo, lost_hi,
+                             d_out, d_lost_bits, stream);
+}
+
+extern "C" int scldpc_peel_sweep_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                              const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                              int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
+                                              int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+{
+    return launch_peel_sweep(p, ntrials, d_vn_adj16, true, d_chan_bits, total_size, sweep_start, lost_lo, lost_hi,
+                             d_out, d_lost_bits, stream);
+}

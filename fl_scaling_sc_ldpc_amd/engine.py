@@ -193,3 +193,50 @@ def pack_bits(bits):
     if pad:
         bits = np.concatenate([bits, np.zeros(bits.shape[:-1] + (pad,), np.uint8)], axis=-1)
     return np.packbits(bits, axis=-1, bitorder="little").view(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Python peeling path (PD)
+# ------------------------------------------------------------------------------------------------
+def peel_sweep(p, d_adj, d_chan, total_size, sweep_start=0, lost_lo=0, lost_hi=None, want_lost=False):
+    """One trial of simulate_sc_ldpc's loop body per batch entry (PD:650-691).  Returns dict with
+    out int32 [T,8] ([0] #lost, [1] #lost_exp, [2] #blocks_failed_exp, [5] rounds, [7] #erased) and `lost` bits."""
+    _require_gpu()
+    T = d_adj.shape[0]
+    assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    dev = d_adj.device
+    out = torch.empty((T, 8), dtype=torch.int32, device=dev)
+    lost = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_lost else None
+    fn = lib().scldpc_peel_sweep_device_adj16 if _is_adj16(d_adj) else lib().scldpc_peel_sweep_device
+    check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(total_size), int(sweep_start), int(lost_lo),
+             int(total_size if lost_hi is None else lost_hi), out.data_ptr(),
+             lost.data_ptr() if lost is not None else None, _stream_ptr(dev)))
+    return {"out": out, "lost": lost}
+
+
+def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, trial0=0, want_r1=True):
+    """One trial of simulate_peeling_decoder_ldpc's loop body per batch entry (PD:750-785).
+    mt_state: int32/uint32-as-int32 tensor [T,625] (CPython MT19937 state, updated in place) or None (Philox)."""
+    _require_gpu()
+    T = d_adj.shape[0]
+    assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
+    dev = d_adj.device
+    out = torch.empty((T, 4), dtype=torch.int32, device=dev)
+    r1 = torch.empty((T, num_steps + 1), dtype=torch.int32, device=dev) if want_r1 else None
+    if mt_state is not None:
+        assert mt_state.is_cuda and mt_state.dtype == torch.int32 and tuple(mt_state.shape) == (T, 625)
+    fn = lib().scldpc_peel_pick_device_adj16 if _is_adj16(d_adj) else lib().scldpc_peel_pick_device
+    check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(total_size), int(num_steps),
+             mt_state.data_ptr() if mt_state is not None else None, int(seed), int(trial0),
+             r1.data_ptr() if r1 is not None else None, out.data_ptr(), _stream_ptr(dev)))
+    return {"out": out, "r1": r1}
+
+
+def r1_moments(d_r1, moments=None):
+    """(cnt, Σr1, Σr1²) per step over a batch of trajectories, accumulated into int64 [3, steps+1]."""
+    T, ncols = d_r1.shape
+    if moments is None:
+        moments = torch.zeros((3, ncols), dtype=torch.int64, device=d_r1.device)
+    check(lib().scldpc_r1_moments_device(T, ncols, d_r1.data_ptr(), moments.data_ptr(), _stream_ptr(d_r1.device)))
+    return moments

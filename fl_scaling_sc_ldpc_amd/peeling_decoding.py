@@ -1,0 +1,339 @@
+"""Host-side mirror of the reference's Python peeling simulators
+(simulators_sc_ldpc/peeling_decoding/peeling_decoding.py = PD): same function names, argument meaning, return
+tuples, argv contracts and output formats — with the per-trial work (sweep peeling + stopping-set components,
+random-pick peeling with the degree-1 trajectory) done by the HIP kernels of libscldpc_hip.so.
+
+    simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is_tail_biting,
+                     num_repeats=int(1e5), max_fuckups=2000, doping_points=[])          → 13-tuple   (PD:591-701)
+    simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_protograph,
+                                  num_repeats=None, doping_points=[])                   → (None, r1, plrs)  (PD:705-789)
+    main_simulate_sc_ldpc()   = ber_sim.py            (PD:1327-1356)
+    main_simulate_variance()  = simulate_variance.py  (PD:1264-1294)
+    test_sc_ldpc()            = `python3 peeling_decoding.py`  (PD:1212-1245)
+
+Two sampling modes (keyword `rng`, not in the reference's signatures):
+  * rng="numpy" (default): the reference's own streams — the GLOBAL numpy RandomState for codes and channels
+    (sc_ldpc.gen_slots → np.random.permutation, np.random.rand; PD:153-154) and the GLOBAL Python `random` for the
+    picks (random.choice, PD:1026).  After `np.random.seed(s); random.seed(s)` the results equal the reference's
+    bit for bit, and both streams are left exactly where the reference leaves them.
+  * rng="philox": codes, channels and picks drawn on the device (counter-based, keyed by (seed, trial)); same
+    ensemble law, any batch size / GPU count gives the same numbers.
+Protograph and tail-biting ensembles (flags P, TB) are outside this path's scope and raise NotImplementedError.
+"""
+import ast
+import pickle
+import random
+import sys
+
+import numpy as np
+import torch
+
+from . import engine as E
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling with the reference's own streams (sc_ldpc.py:22-56; PD:147-195)
+# ------------------------------------------------------------------------------------------------
+def gen_slots(l, r, L, M):
+    """sc_ldpc.gen_slots from the global numpy stream: `transmissions` int32 [L*M, l]."""
+    num_cns = int(l * M / r)
+    D = L + l - 1
+    cn = np.stack([i * num_cns + np.random.permutation(l * M).reshape(l, M) // r for i in range(D)])
+    tr = np.empty((L, M, l), dtype=np.int32)
+    for d in range(l):
+        tr[:, :, d] = cn[d:d + L, d, :]
+    return tr.reshape(L * M, l)
+
+
+def gen_erasures(e, L, M, doping_points):
+    """np.random.rand(L*M) <= e (PD:154) with hard / soft doping applied (PD:166-195)."""
+    mask = np.random.rand(L * M) <= e
+    if isinstance(doping_points, dict):
+        for pos, alpha in doping_points.items():
+            mask[pos * M: pos * M + int(alpha * M)] = False
+    elif len(doping_points):
+        mask &= ~np.isin(np.arange(L * M) // M, list(doping_points))
+    return mask
+
+
+def _check_flags(is_protograph, is_tail_biting=False):
+    if is_protograph or is_tail_biting:
+        raise NotImplementedError("protograph / tail-biting ensembles are not part of the accelerated path")
+
+
+def _doped_positions(doping_points):
+    return sorted(doping_points.keys()) if isinstance(doping_points, dict) else list(doping_points)
+
+
+class _Geometry:
+    """The index bookkeeping of simulate_sc_ldpc (PD:604-611, 635-648)."""
+
+    def __init__(self, l, r, L, M, is_terminated, is_bounded, doping_points):
+        self.ignored_head = 0 if is_bounded else 20
+        self.ignored_head_schedule = 0 if is_bounded else 10
+        self.ignored_tail = 0 if is_terminated else 20
+        self.L = L + self.ignored_head + self.ignored_tail
+        self.cpp = int(l / r * M)
+        self.num_positions = self.L + l - 1 if is_terminated else self.L
+        self.total_size = self.cpp * self.num_positions
+        nd = len(doping_points)
+        if isinstance(doping_points, dict):
+            self.generated = (self.L - self.ignored_head - self.ignored_tail) * M - \
+                sum(int(a * M) for a in doping_points.values())
+        else:
+            self.generated = (self.L - nd - self.ignored_head - self.ignored_tail) * M
+        self.blocks = self.L - nd - self.ignored_head - self.ignored_tail
+        self.params = E.CodeParams(l, r, self.L, self.cpp, M)
+        self.sweep_start = self.ignored_head_schedule * self.cpp
+        self.lost_lo = self.cpp * self.ignored_head
+        self.lost_hi = self.total_size - self.cpp * self.ignored_tail
+
+
+def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is_tail_biting, num_repeats=int(1e5),
+                     max_fuckups=2000, doping_points=[], rng="numpy", seed=0, batch=None, device="cuda:0"):
+    """Error-rate Monte-Carlo of the sweep peeling decoder (PD:591-701); returns the reference's 13-tuple."""
+    _check_flags(is_protograph, is_tail_biting)
+    g = _Geometry(l, r, L, M, is_terminated, is_bounded, doping_points)
+    p = g.params
+    if batch is None:
+        batch = 64 if rng == "numpy" else 2048
+    num_fuckups = num_fuckups_truncated = 0
+    total_generated = total_failed = total_failed_expurgated = 0
+    total_blocks_generated = total_blocks_failed_exp = 0
+    done = 0
+    while done < num_repeats:
+        nb = min(batch, num_repeats - done)
+        states = None
+        if rng == "numpy":
+            adj = np.empty((nb, p.n, l), dtype=np.int32)
+            ch = np.empty((nb, p.nw), dtype=np.uint32)
+            states = []
+            for t in range(nb):
+                adj[t] = gen_slots(l, r, g.L, M)
+                ch[t] = E.pack_bits(gen_erasures(e, g.L, M, doping_points).astype(np.uint8))
+                states.append(np.random.get_state())
+            d_adj, d_ch = E.to_device(adj, ch, device)
+        elif rng == "philox":
+            if isinstance(doping_points, dict):
+                raise NotImplementedError("soft doping needs the host sampler (rng='numpy')")
+            d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, _doped_positions(doping_points), device=device, adj16=True)
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        out = E.peel_sweep(p, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"].cpu().numpy()
+        # ordered accumulation with the reference's stop rule (PD:668-699)
+        used = nb
+        for t in range(nb):
+            lost, lost_exp, blocks_exp = int(out[t, 0]), int(out[t, 1]), int(out[t, 2])
+            total_generated += g.generated
+            total_blocks_generated += g.blocks
+            num_fuckups += lost >= 1
+            total_failed += lost
+            num_fuckups_truncated += lost_exp > 0
+            total_failed_expurgated += lost_exp
+            total_blocks_failed_exp += blocks_exp
+            if num_fuckups >= max_fuckups:
+                used = t + 1
+                break
+        done += used
+        if used < nb or num_fuckups >= max_fuckups:
+            if states is not None:
+                np.random.set_state(states[used - 1])       # leave the stream where the reference stops drawing
+            break
+    o1 = done
+    failures, gens = np.zeros(num_repeats), np.zeros(num_repeats)
+    return (num_fuckups / o1, num_fuckups_truncated / o1, total_failed / total_generated,
+            total_failed_expurgated / total_generated, num_fuckups_truncated, o1, total_failed_expurgated,
+            total_generated, failures, gens, total_blocks_failed_exp, total_blocks_generated,
+            total_blocks_failed_exp / total_blocks_generated)
+
+
+def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_protograph, num_repeats=None,
+                                  doping_points=[], rng="numpy", seed=0, batch=256, device="cuda:0",
+                                  want_moments=False):
+    """Random-pick peeling with the degree-1-CN trajectory (PD:705-789): returns (None, r1, plrs) with
+    r1 int64 [num_repeats, num_pd_steps+1] and plrs float64 [num_repeats].  want_moments=True (philox mode) returns
+    (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories."""
+    _check_flags(is_protograph)
+    if not num_repeats:
+        num_repeats = 100
+    if isinstance(doping_points, dict):
+        raise NotImplementedError("simulate_peeling_decoder_ldpc takes hard doping points only (PD:747)")
+    cpp = int(l_deg / r_deg * M)
+    num_positions = L + l_deg - 1 if is_terminated else L
+    total_size = cpp * num_positions
+    num_pd_steps = int(M * num_positions * (e + 0.1))                      # PD:721
+    nd = len(doping_points)
+    p = E.CodeParams(l_deg, r_deg, L, cpp, M)
+    total_generated = (L - nd) * M                                         # PD:747
+    plrs = np.zeros(num_repeats)
+    if rng == "numpy":
+        r1 = np.zeros((num_repeats, num_pd_steps + 1), dtype="int")
+        for o in range(num_repeats):                                       # one shared `random` stream: sequential
+            adj = gen_slots(l_deg, r_deg, L, M)
+            mask = gen_erasures(e, L, M, doping_points)
+            d_adj, d_ch = E.to_device(adj[None], E.pack_bits(mask.astype(np.uint8))[None], device)
+            st = random.getstate()
+            mt = torch.from_numpy(np.array(st[1], dtype=np.uint32).view(np.int32).copy()[None]).to(device)
+            res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=mt)
+            new = mt.cpu().numpy().view(np.uint32)[0]
+            random.setstate((st[0], tuple(int(x) for x in new), st[2]))
+            r1[o] = res["r1"][0].cpu().numpy()
+            n_users, picked = (int(x) for x in res["out"][0, :2].cpu())
+            plrs[o] = (n_users - picked) / total_generated               # (generated − recovered)/generated, PD:753,785
+            if r1[o, -1] == 1:
+                print("The number of degree-1 CNs at the end of the iterations is 1!!!")
+        return None, r1, plrs
+    if rng != "philox":
+        raise ValueError("rng must be 'numpy' or 'philox'")
+    r1_all = None if want_moments else np.zeros((num_repeats, num_pd_steps + 1), dtype="int")
+    moments = None
+    for done in range(0, num_repeats, batch):
+        nb = min(batch, num_repeats - done)
+        d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device, adj16=True)
+        res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done)
+        o = res["out"].cpu().numpy()
+        plrs[done:done + nb] = (o[:, 0] - o[:, 1]) / total_generated
+        if want_moments:
+            moments = E.r1_moments(res["r1"], moments)
+        else:
+            r1_all[done:done + nb] = res["r1"].cpu().numpy()
+    return None, (moments.cpu().numpy() if want_moments else r1_all), plrs
+
+
+# ------------------------------------------------------------------------------------------------
+# variance reduction (fl_scaling/est_scaling_params.py:42-49, 90-94, 131-138)
+# ------------------------------------------------------------------------------------------------
+def nu_chunk_from_moments(moments, r1s_theory, M):
+    """calc_nu_chunk from the integer moments (cnt, Σr1, Σr1²) of a batch: ssquares[s] = Σ_{r1≠0} (r1/M − θ/M)²,
+    counts[s] = cnt[s], over the support of the theory curve.  Equal to the reference's nansum up to float rounding
+    (relative 1e-12; the reference sums squared float differences, this sums integers first)."""
+    last = int(np.max(np.where(r1s_theory > 0))) + 1
+    th = r1s_theory[r1s_theory > 0].astype(np.float64)
+    cnt, s1, s2 = (moments[k][:last][:r1s_theory.shape[0]].astype(np.float64) for k in range(3))
+    return (s2 - 2.0 * th * s1 + cnt * th * th) / (M * M), moments[0][:last][:r1s_theory.shape[0]].astype(np.int64)
+
+
+class _ArraysOnly(pickle.Unpickler):
+    """The theory file is a pickle of numpy arrays (NB cell 20); nothing else is allowed to load."""
+    _OK = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+           ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"),
+           ("numpy._core.multiarray", "scalar")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._OK:
+            raise pickle.UnpicklingError(f"refusing to load {module}.{name}: theory files hold numpy arrays only")
+        return super().find_class(module, name)
+
+
+def load_theory(path):
+    if path.endswith(".npy"):
+        return np.load(path)
+    with open(path, "rb") as f:
+        return np.asarray(_ArraysOnly(f).load()[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# command-line entry points
+# ------------------------------------------------------------------------------------------------
+_SAFE_CALLS = {"arange": np.arange, "linspace": np.linspace, "range": range, "list": list}
+
+
+def _safe_eval(text):
+    """The reference eval()s its `es` and `doping_points` arguments (PD:1333,1340).  Same inputs accepted —
+    numbers, lists/tuples/dicts, arithmetic, np.arange/np.linspace/range — without executing arbitrary code."""
+    def ev(node):
+        if isinstance(node, ast.Expression):
+            return ev(node.body)
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            return node.value
+        if isinstance(node, (ast.List, ast.Tuple)):
+            return [ev(x) for x in node.elts]
+        if isinstance(node, ast.Dict):
+            return {ev(k): ev(v) for k, v in zip(node.keys, node.values)}
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            v = ev(node.operand)
+            return -v if isinstance(node.op, ast.USub) else v
+        if isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+            a, b = ev(node.left), ev(node.right)
+            return {ast.Add: a + b, ast.Sub: a - b, ast.Mult: a * b, ast.Div: a / b}[type(node.op)] \
+                if not isinstance(node.op, ast.Div) or b != 0 else a / b
+        if isinstance(node, ast.Call) and not node.keywords:
+            f = node.func
+            name = f.attr if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in ("np", "numpy") \
+                else (f.id if isinstance(f, ast.Name) else None)
+            if name in _SAFE_CALLS:
+                return _SAFE_CALLS[name](*[ev(x) for x in node.args])
+        raise ValueError("unsupported expression in argument: " + ast.dump(node)[:80])
+    return ev(ast.parse(text, mode="eval"))
+
+
+def main_simulate_sc_ldpc(argv=None, **kw):
+    """ber_sim.py: OUT l r L M "es" T|N U|P B|N TB|NTB num_repeats max_fuckups "doping" (PD:1327-1356)."""
+    a = sys.argv if argv is None else [None] + list(argv)
+    fname, l, r, L, M = a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5])
+    es = _safe_eval(a[6])
+    is_terminated, is_protograph = a[7] == "T", a[8] == "P"
+    is_bounded, is_tail_biting = a[9] == "B", a[10] == "TB"
+    num_repeats, max_fuckups = int(a[11]), int(a[12])
+    doping_points = _safe_eval(a[13])
+    L += len(doping_points)                                                 # PD:1343
+    head = (f"# SC-LDPC ({l},{r},L={L},M={M}) terminated:{is_terminated}, proto:{is_protograph}, bounded:{is_bounded}, "
+            f"tail biting:{is_tail_biting}. num_repeats={num_repeats}, max_fuckups={max_fuckups}, "
+            f"doping_points={doping_points}.")
+    with open(fname, "wt") as f:
+        print(head)
+        print(head, file=f)
+        f.flush()
+        for e in (es if isinstance(es, (list, np.ndarray, range)) else [es]):
+            ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, _flrs, _gens, fblocks, tblocks, bler = \
+                simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is_tail_biting, num_repeats,
+                                 max_fuckups, doping_points, **kw)
+            print(e, ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, fblocks, tblocks, bler, file=f)
+            print(e, ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, fblocks, tblocks, bler)
+            f.flush()
+            sys.stdout.flush()
+
+
+def main_simulate_variance(argv=None, **kw):
+    """simulate_variance.py: OUT l r L M e T|N U|P num_runs num_runs_batch THEORY (PD:1264-1294): writes
+    pickle.dump((ssquares, counts))."""
+    a = sys.argv if argv is None else [None] + list(argv)
+    fname, l, r, L, M, e = a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6])
+    is_terminated, is_protograph = a[7] == "T", a[8] == "P"
+    num_runs, num_runs_batch, ftheory = int(a[9]), int(a[10]), a[11]
+    r1s_theory = load_theory(ftheory)
+    ssquares, counts = None, None
+    for i in range(int(num_runs / num_runs_batch)):
+        if kw.get("rng", "numpy") == "philox":
+            _, mom, _ = simulate_peeling_decoder_ldpc(e, l, r, L, M, is_terminated, is_protograph, num_runs_batch,
+                                                      want_moments=True, **dict(kw, seed=kw.get("seed", 0) + i))
+        else:
+            _, r1s, _ = simulate_peeling_decoder_ldpc(e, l, r, L, M, is_terminated, is_protograph, num_runs_batch, **kw)
+            mom = E.r1_moments(torch.from_numpy(r1s.astype(np.int32)).to(kw.get("device", "cuda:0"))).cpu().numpy()
+        ss, cn = nu_chunk_from_moments(mom, r1s_theory, M)
+        ssquares = ss if ssquares is None else ssquares + ss
+        counts = cn if counts is None else counts + cn
+    with open(fname, "wb") as f:
+        pickle.dump((ssquares, counts), f)
+    return ssquares, counts
+
+
+def test_sc_ldpc(l=4, r=8, L=50, M=10000, e=0.48, is_terminated=False, num_runs=100, num_runs_batch=100,
+                 out_pattern="r1_sc_ldpc_{l}_{r}_{L}_{M}_{etag}_{term}_{i}.pkl", **kw):
+    """`python3 peeling_decoding.py` (PD:1212-1245): batches of trajectories pickled as (r1, plrs)."""
+    for i in range(int(num_runs / num_runs_batch)):
+        _, r1, plrs = simulate_peeling_decoder_ldpc(e, l, r, L, M, is_terminated, False, num_runs_batch, [], **kw)
+        name = out_pattern.format(l=l, r=r, L=L, M=M, etag=("%.3f" % e).replace(".", "")[:4],
+                                  term="terminated" if is_terminated else "nonterminated", i=i)
+        with open(name, "wb") as f:
+            pickle.dump((r1, plrs), f)
+
+
+if __name__ == "__main__":
+    prog = sys.argv[1] if len(sys.argv) > 1 else "test_sc_ldpc"
+    if prog == "ber_sim":
+        main_simulate_sc_ldpc(sys.argv[2:])
+    elif prog == "simulate_variance":
+        main_simulate_variance(sys.argv[2:])
+    else:
+        test_sc_ldpc()

@@ -151,6 +151,53 @@ int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                               int32_t W, int32_t max_it, int32_t init_it,
                               int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Python peeling path (PD = simulators_sc_ldpc/peeling_decoding/peeling_decoding.py)
+ * In PD's vocabulary VN = "user", CN = "slot"; `M` = vns_pos, cns_per_pos = cns_pos, `transmissions`
+ * = vn_adj.  The graph is always laid out for the full terminated chain (ncn = (L+dv-1)*cns_pos CN words);
+ * total_size = cns_pos*(L+dv-1) for a terminated chain or cns_pos*L for a non-terminated one (PD:609-611).
+ * ------------------------------------------------------------------------------------------- */
+
+/* One trial of simulate_sc_ldpc's loop body (PD:650-691): sweep peeling
+ * `for t in range(sweep_start, total_size): sic_round(schedule, t)` (PD:656-657, 270-313), then
+ * lost = VNs still attached to a CN of [lost_lo, lost_hi) whose CNs are all < total_size (PD:659-666),
+ * stopping sets = connected components of `lost` (extract_stopping_sets, PD:1077-1095).
+ * d_out int32 [ntrials][8]: [0] #lost, [1] #lost in components of more than 2 VNs (num_lost_exp, PD:680),
+ * [2] #distinct positions int(birthday/cns_per_pos) over those components (PD:684-689), [5] peeling rounds,
+ * [7] #erased VNs handed in; the other slots are 0.  d_lost_bits (optional) receives the lost set. */
+int scldpc_peel_sweep_device(const scldpc_code_params *p, int32_t ntrials,
+                             const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                             int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
+                             int32_t *d_out, uint32_t *d_lost_bits, void *stream);
+int scldpc_peel_sweep_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                   const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                   int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
+                                   int32_t *d_out, uint32_t *d_lost_bits, void *stream);
+
+/* One trial of simulate_peeling_decoder_ldpc's loop body (PD:750-785): random-pick peeling with the
+ * degree-1-CN trajectory.  num_steps = int(M*num_positions*(e+0.1)) (PD:721).
+ * Generator: d_mt_state != NULL ⇒ uint32 [ntrials][625] = CPython `random` MT19937 state (624 words + index,
+ * as random.getstate() gives it); every pick draws `_randbelow(#degree-1 CNs)` from it exactly as
+ * random.choice does (PD:1026) and the advanced state is written back, so a host loop can chain the trials of
+ * one reference run.  d_mt_state == NULL ⇒ Philox4x32-10 keyed by (seed, trial0 + trial), same rejection rule.
+ * d_r1 (optional) int32 [ntrials][num_steps+1] = r1[o, :] (PD:758,781).  d_out int32 [ntrials][4]:
+ * #erased VNs, #picks, last r1 value, #steps that had a degree-1 CN. */
+int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntrials,
+                            const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                            int32_t total_size, int32_t num_steps,
+                            uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
+                            int32_t *d_r1, int32_t *d_out, void *stream);
+int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                  const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                  int32_t total_size, int32_t num_steps,
+                                  uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
+                                  int32_t *d_r1, int32_t *d_out, void *stream);
+
+/* Integer moments of a batch of trajectories, the device half of main_simulate_variance (PD:1264-1294) /
+ * calc_nu_chunk (fl_scaling/est_scaling_params.py:90-94,131-138): d_moments int64 [3][ncols], accumulated in
+ * place: [0][s] += #{r1[t][s] != 0}, [1][s] += Σ_t r1[t][s], [2][s] += Σ_t r1[t][s]². */
+int scldpc_r1_moments_device(int32_t ntrials, int32_t ncols, const int32_t *d_r1, int64_t *d_moments, void *stream);
+
 /* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
  * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),
  * where k is the first trial at which frame_err reaches stop_frame_err (all trials if it never does

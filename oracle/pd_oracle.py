@@ -228,3 +228,19 @@ def calc_nu_chunk(r1s, r1s_theory, M):
     d = x - th / M
     d[x == 0] = np.nan                                                    # :135
     return np.nansum(d ** 2, axis=0), np.sum(~np.isnan(d), axis=0)        # :136-137
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU twin of the device's Philox pick stream (csrc/peel_pick.hip, rng_mode 1): draw i of trial t is word (i & 3)
+# of philox4x32_10(counter = (i >> 2, 0x90000000, t_lo, t_hi), key = seed); getrandbits(k) = word >> (32 - k).
+# ------------------------------------------------------------------------------------------------
+class PhiloxPickStream:
+    def __init__(self, seed, trial):
+        from oracle import oracle as O
+        self._f, self.seed, self.trial, self.i = O.philox4x32_10, seed, trial, 0
+
+    def getrandbits(self, k):
+        w = self._f([self.i >> 2, 0x90000000, self.trial & 0xFFFFFFFF, self.trial >> 32],
+                    [self.seed & 0xFFFFFFFF, self.seed >> 32])[self.i & 3]
+        self.i += 1
+        return w >> (32 - k)

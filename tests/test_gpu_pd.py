@@ -1,0 +1,178 @@
+"""Parity of the Python-peeling mirror (-m gpu): fl_scaling_sc_ldpc_amd.peeling_decoding, driving the HIP kernels
+peel_sweep / peel_pick / r1_moments through the C-ABI, against
+  (a) golden vectors produced by importing the REAL reference (tests/golden/pd_*.npz) on identical seeds, and
+  (b) the numpy oracle (oracle/pd_oracle.py) on device-sampled inputs."""
+import glob
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, require_gpu
+
+pytestmark = pytest.mark.gpu
+ER = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_er_*.npz")))
+TR = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_tr_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def PD():
+    require_gpu()
+    from fl_scaling_sc_ldpc_amd import peeling_decoding
+    return peeling_decoding
+
+
+def _load(path):
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    doping = m["doping"]
+    if m.get("doping_soft"):
+        doping = {int(k): v for k, v in doping.items()}
+    return z, m, doping
+
+
+def _tuple11(t):
+    return np.array([t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[10], t[11], t[12]], dtype=np.float64)
+
+
+@pytest.mark.parametrize("path", ER, ids=[os.path.basename(p)[:-4] for p in ER])
+def test_simulate_sc_ldpc_equals_reference_on_identical_seeds(PD, path):
+    z, m, doping = _load(path)
+    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], False, m["is_bounded"], False)
+    for k, s in enumerate(z["seed"]):
+        np.random.seed(int(s)); random.seed(int(s))
+        t = PD.simulate_sc_ldpc(*args, num_repeats=1, max_fuckups=2000, doping_points=doping)
+        assert np.array_equal(_tuple11(t), z["tuple11"][k]), (path, s, _tuple11(t), z["tuple11"][k])
+        assert len(t) == 13 and t[8].shape == (1,) and t[9].shape == (1,)
+    # several trials from one stream, in one device batch
+    np.random.seed(int(z["seed"][0])); random.seed(int(z["seed"][0]))
+    t = PD.simulate_sc_ldpc(*args, num_repeats=3, max_fuckups=2000, doping_points=doping)
+    assert np.array_equal(_tuple11(t), z["multi3"])
+
+
+def test_simulate_sc_ldpc_stop_rule_leaves_the_stream_where_the_reference_does(PD, oracle):
+    from oracle import pd_oracle as P
+    # max_fuckups = 2 at an ε where most trials fail: the call must stop after the 2nd failing trial,
+    # whatever the device batch size, and the global numpy stream must sit right after that trial's draws.
+    for batch in (1, 3, 64):
+        np.random.seed(5)
+        t = PD.simulate_sc_ldpc(0.5, 4, 8, 10, 20, True, False, True, False, num_repeats=40, max_fuckups=2, batch=batch)
+        after = np.random.rand()
+        ref = P.simulate_sc_ldpc(5, 0.5, 4, 8, 10, 20, True, True, 40, 2)
+        assert np.array_equal(_tuple11(t), np.array(ref))
+        rs = np.random.RandomState(5)
+        for _ in range(int(ref[5])):
+            P.gen_slots(rs, 4, 8, 10, 20); rs.rand(200)
+        assert after == rs.rand()
+
+
+@pytest.mark.parametrize("path", TR, ids=[os.path.basename(p)[:-4] for p in TR])
+def test_random_pick_trajectories_equal_reference_on_identical_seeds(PD, path):
+    z, m, doping = _load(path)
+    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], False)
+    seeds = z["seed"] if m["M"] <= 200 else z["seed"][:2]
+    for k, s in enumerate(seeds):
+        np.random.seed(int(s)); random.seed(int(s))
+        none, r1, plrs = PD.simulate_peeling_decoder_ldpc(*args, 1, doping)
+        assert none is None and r1.shape == z["r1"][k:k + 1].shape
+        assert (r1[0] == z["r1"][k]).all() and plrs[0] == z["plr"][k], (path, s)
+    # two trials from the shared numpy + `random` streams; both streams end where the reference leaves them
+    s0 = int(z["seed"][0])
+    np.random.seed(s0); random.seed(s0)
+    _, r1, plrs = PD.simulate_peeling_decoder_ldpc(*args, 2, doping)
+    assert (r1 == z["multi2_r1"]).all() and (plrs == z["multi2_plr"]).all()
+
+
+def test_python_random_stream_is_advanced_exactly(PD):
+    from oracle import pd_oracle as P
+    np.random.seed(9); random.seed(9)
+    _, r1, _ = PD.simulate_peeling_decoder_ldpc(0.45, 4, 8, 10, 20, False, False, 3, [])
+    got = [random.random() for _ in range(3)]
+    rng = random.Random(9)
+    rs = np.random.RandomState(9)
+    for _ in range(3):
+        tr = P.gen_slots(rs, 4, 8, 10, 20); mask = P.gen_erasures(rs, 0.45, 4, 8, 10, 20)
+        P.random_pick_trial(tr, mask, 4, 8, 10, 20, 0.45, False, rng)
+    assert got == [rng.random() for _ in range(3)]
+
+
+@pytest.mark.parametrize("L,M,e,term,bounded", [(12, 40, 0.47, True, True), (12, 40, 0.47, False, False),
+                                                (50, 1000, 0.48, True, True), (20, 200, 0.5, False, True)])
+def test_peel_sweep_equals_oracle_on_device_sampled_inputs(PD, L, M, e, term, bounded):
+    from oracle import pd_oracle as P
+    E = PD.E
+    g = PD._Geometry(4, 8, L, M, term, bounded, [])
+    T = 6 if M >= 1000 else 24
+    d_adj, d_ch = E.sample_philox(g.params, 77, 1000, T, e, adj16=True)
+    res = E.peel_sweep(g.params, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi, want_lost=True)
+    out = res["out"].cpu().numpy()
+    A = E.adj16_to_global(g.params, d_adj.cpu().numpy())
+    bits = E.unpack_bits(d_ch.cpu().numpy(), g.params.n).astype(bool)
+    lost_bits = E.unpack_bits(res["lost"].cpu().numpy(), g.params.n)
+    for t in range(T):
+        s = P.sc_ldpc_trial_stats(A[t].astype(np.int64), bits[t], 4, 8, L, M, term, bounded)
+        assert (out[t, 0], out[t, 1], out[t, 2], out[t, 7]) == (s["num_lost"], s["num_lost_exp"], s["blocks_failed_exp"],
+                                                               bits[t].sum()), (L, M, t)
+        assert lost_bits[t].sum() == s["num_lost"]
+    # the mirror in philox mode returns the same totals
+    t13 = PD.simulate_sc_ldpc(e, 4, 8, L, M, term, False, bounded, False, num_repeats=T, rng="philox", seed=77, batch=4)
+    assert t13[5] == T and t13[7] == T * g.generated
+
+
+@pytest.mark.parametrize("L,M,e,term", [(10, 20, 0.45, False), (10, 20, 0.5, True), (20, 200, 0.47, False)])
+def test_peel_pick_philox_stream_equals_cpu_twin(PD, oracle, L, M, e, term):
+    from oracle import pd_oracle as P
+    E = PD.E
+    T = 5
+    none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=31, batch=3)
+    p = E.CodeParams(4, 8, L, M // 2, M)
+    d_adj, d_ch = E.sample_philox(p, 31, 0, T, e, adj16=True)
+    A = E.adj16_to_global(p, d_adj.cpu().numpy()).astype(np.int64)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n).astype(bool)
+    for t in range(T):
+        ref_r1, ref_plr = P.random_pick_trial(A[t], bits[t], 4, 8, L, M, e, term, P.PhiloxPickStream(31, t))
+        assert (r1[t] == ref_r1).all() and plrs[t] == ref_plr, (L, M, t)
+
+
+def test_moments_and_variance_chunk(PD):
+    from oracle import pd_oracle as P
+    import torch
+    E = PD.E
+    rng = np.random.RandomState(1)
+    r1 = rng.randint(0, 300, size=(37, 500)).astype(np.int32)
+    r1[:, 400:] = 0
+    mom = E.r1_moments(torch.from_numpy(r1).cuda())
+    mom = E.r1_moments(torch.from_numpy(r1[:5]).cuda(), mom).cpu().numpy()          # accumulates in place
+    both = np.concatenate([r1, r1[:5]]).astype(np.int64)
+    assert (mom[0] == (both != 0).sum(0)).all() and (mom[1] == both.sum(0)).all() and (mom[2] == (both ** 2).sum(0)).all()
+    theory = np.concatenate([np.linspace(250, 3, 380), np.zeros(120)])
+    ss, cnt = PD.nu_chunk_from_moments(mom, theory, 1000)
+    ss_ref, cnt_ref = P.calc_nu_chunk(both, theory, 1000)
+    assert (cnt == cnt_ref).all() and np.allclose(ss, ss_ref, rtol=1e-12, atol=0)     # float tolerance: 1e-12 relative
+
+
+def test_ber_sim_cli_writes_the_reference_rows(PD, tmp_path):
+    from oracle import pd_oracle as P
+    out = tmp_path / "ber.dat"
+    np.random.seed(3)
+    PD.main_simulate_sc_ldpc([str(out), "4", "8", "10", "20", "[0.5, 0.45]", "T", "U", "B", "NTB", "6", "2000", "[4]"])
+    lines = open(out).read().strip().split("\n")
+    assert lines[0] == ("# SC-LDPC (4,8,L=11,M=20) terminated:True, proto:False, bounded:True, tail biting:False. "
+                        "num_repeats=6, max_fuckups=2000, doping_points=[4].")
+    rs_seed = 3
+    # the two ε points share one numpy stream (PD:1348-1350): replay them back to back with the oracle
+    rs = np.random.RandomState(rs_seed)
+    for row, e in zip(lines[1:], (0.5, 0.45)):
+        acc = np.zeros(7)
+        for _ in range(6):
+            tr = P.gen_slots(rs, 4, 8, 11, 20); mask = P.gen_erasures(rs, e, 4, 8, 11, 20, [4])
+            s = P.sc_ldpc_trial_stats(tr, mask, 4, 8, 11, 20, True, True, [4])
+            acc += [s["frame_err"], s["frame_err_exp"], s["num_lost"], s["num_lost_exp"], s["generated"],
+                    s["blocks_failed_exp"], s["blocks"]]
+        exp = (e, acc[0] / 6, acc[1] / 6, acc[2] / acc[4], acc[3] / acc[4], int(acc[1]), 6, int(acc[3]), int(acc[4]),
+               int(acc[5]), int(acc[6]), acc[5] / acc[6])
+        assert row == " ".join(str(x) for x in exp)
+    with pytest.raises(NotImplementedError):
+        PD.simulate_sc_ldpc(0.4, 4, 8, 10, 20, True, True, True, False, 1)
