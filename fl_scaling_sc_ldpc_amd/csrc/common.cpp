@@ -30,6 +30,28 @@ int check_params(const scldpc_code_params *p)
     return SCLDPC_OK;
 }
 
+static void *g_ws[16] = {nullptr};
+static size_t g_ws_bytes[16] = {0};
+
+int workspace(size_t bytes, void **out)
+{
+    int dev = 0;
+    SCLDPC_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return set_error(SCLDPC_ERR_BAD_ARG, "device ordinal %d out of range", dev);
+    if (bytes > g_ws_bytes[dev]) {
+        if (g_ws[dev]) {
+            SCLDPC_HIP_CHECK(hipDeviceSynchronize());
+            SCLDPC_HIP_CHECK(hipFree(g_ws[dev]));
+            g_ws[dev] = nullptr; g_ws_bytes[dev] = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        SCLDPC_HIP_CHECK(hipMalloc(&g_ws[dev], want));
+        g_ws_bytes[dev] = want;
+    }
+    *out = g_ws[dev];
+    return SCLDPC_OK;
+}
+
 }  // namespace scldpc
 
 extern "C" int scldpc_abi_version(void) { return SCLDPC_ABI_VERSION; }

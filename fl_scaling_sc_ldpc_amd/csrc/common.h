@@ -17,6 +17,10 @@ inline int nw_of(const scldpc_code_params *p) { return (n_of(p) + 31) / 32; }
 // 0 when the geometry is one the reference's generate_code can produce (BPF:1656-1716).
 int check_params(const scldpc_code_params *p);
 
+// Library-owned device scratch (CN words of ensembles beyond the LDS budget): one allocation per process and
+// device, grown on demand (never inside a stream capture: a growth synchronises the device before freeing).
+int workspace(size_t bytes, void **out);
+
 constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
 #define SCLDPC_HIP_CHECK(expr)                                                                     \

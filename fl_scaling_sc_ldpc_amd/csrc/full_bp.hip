@@ -41,6 +41,7 @@ struct Args {
     uint32_t magic_v, magic_c;      // floor(2^32/d)+1: x/d == umulhi(x, magic) for the ranges used here
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
+    uint32_t *ws;                   // [T][nk] CN words in global memory (WideG only)
     const uint32_t *chan;
     int32_t *counters;
     int32_t *rows;
@@ -50,18 +51,30 @@ struct Args {
 struct Vn { int j, pos, t; };
 
 // ---- CN-word policies --------------------------------------------------------------------------
-struct Wide {
+// G = false: the words live in LDS.  G = true: they live in a global-memory workspace (one nk-word slice per trial,
+// L2-resident while hot) for ensembles whose CN words exceed the LDS — N >= 2500 at (4,8), e.g. bp_traj's shipped
+// Def_M = 2500.  Same algorithm with global atomics; plain reads go past the CU's L1 (agent-scope loads) so that they
+// see what the atomics did in L2.  U, the frontier queues and the scan bitmap stay in LDS either way.
+template <bool G>
+struct WideT {
+    static constexpr bool kGlobal = G;
+    static __host__ __device__ int lds_words(int nk) { return G ? 0 : nk; }
     static __host__ __device__ int words(int nk) { return nk; }
+    static __device__ __forceinline__ uint32_t ld(const uint32_t *st, int c)
+    {
+        if constexpr (G) return __hip_atomic_load(&st[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else             return st[c];
+    }
     static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int, int, bool erased, bool deg)
     {
         atomicAdd(&st[c], (deg ? kDegOne : 0u) + (erased ? kCntOne + (uint32_t)v.j : 0u));
     }
-    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return st[c] >> kCntShift; }
-    static __device__ __forceinline__ uint32_t deg(const uint32_t *st, int c) { return (st[c] >> kDegShift) & kDegMask; }
+    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return ld(st, c) >> kCntShift; }
+    static __device__ __forceinline__ uint32_t deg(const uint32_t *st, int c) { return (ld(st, c) >> kDegShift) & kDegMask; }
     // the single erased neighbour of c (valid only if cnt == 1 in the word that was read); -1 otherwise
     static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &)
     {
-        const uint32_t w = st[c];
+        const uint32_t w = ld(st, c);
         return (w >> kCntShift) == 1u ? (int)(w & kSumMask) : -1;
     }
     static __device__ __forceinline__ uint32_t remove_cnt(uint32_t *st, int c, const Vn &v, int, int)   // returns old cnt
@@ -72,12 +85,16 @@ struct Wide {
     // partner of v at CN c if cnt == 2, else -1
     static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int, const Args &)
     {
-        const uint32_t w = st[c];
+        const uint32_t w = ld(st, c);
         return (w >> kCntShift) == 2u ? (int)((w & kSumMask) - (uint32_t)v.j) : -1;
     }
 };
+using Wide = WideT<false>;
+using WideG = WideT<true>;
 
 struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of word c >> 1
+    static constexpr bool kGlobal = false;
+    static __host__ __device__ int lds_words(int nk) { return (nk + 1) / 2; }
     static __host__ __device__ int words(int nk) { return (nk + 1) / 2; }
     static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int i, int V, bool erased, bool)
     {
@@ -125,7 +142,10 @@ template <class ST, bool TRAJ, int DV, bool A16, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *cn_state = lds + a.lay.cn_state;
+    const int trial = blockIdx.x;
+    uint32_t *cn_state;
+    if constexpr (ST::kGlobal) cn_state = a.ws + (size_t)trial * a.nk;
+    else                       cn_state = lds + a.lay.cn_state;
     uint32_t *U = lds + a.lay.U;
     uint32_t *fbits = lds + a.lay.fbits;
     uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
@@ -134,7 +154,6 @@ __global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
     int *scal = reinterpret_cast<int *>(lds + a.lay.scal);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int trial = blockIdx.x;
     const int n = a.n, nk = a.nk, dv = (DV ? DV : a.dv), cn_lim = a.cn_lim, nw = a.lay.nw, qcap = a.lay.qcap;
     const int V = a.vns_pos;
     const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
@@ -367,7 +386,7 @@ int make_layout(const scldpc_code_params *p, int budget_bytes, Layout *lay)
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };   // keep 16-B alignment
     lay->nw = (n + 31) / 32;
-    lay->cn_state = take(ST::words(nk));
+    lay->cn_state = take(ST::lds_words(nk));
     lay->U = take(lay->nw);
     lay->fbits = take(((nk + 63) / 64) * 2);
     lay->pos_cnt = take(p->L);
@@ -407,8 +426,9 @@ extern "C" int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p)
     if (int rc = scldpc::check_params(p)) return rc;
     Layout lay;
     if (packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &lay) == 0) return 4ll * lay.total;
-    if (make_layout<Wide>(p, scldpc::kMaxLdsBytes, &lay)) return 4ll * (scldpc::nk_of(p) + scldpc::nw_of(p)) + (64 << 10);
-    return 4ll * lay.total;
+    if (make_layout<Wide>(p, scldpc::kMaxLdsBytes, &lay) == 0) return 4ll * lay.total;
+    if (make_layout<WideG>(p, scldpc::kMaxLdsBytes, &lay) == 0) return 4ll * lay.total;   // CN words in the workspace
+    return 4ll * scldpc::nw_of(p) + (64 << 10);
 }
 
 static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
@@ -431,9 +451,17 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     Args a{};
     // two workgroups per CU with the packed CN words when the ensemble allows it (and no trajectory rows)
     const bool packed = !traj && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
-    if (!packed && make_layout<Wide>(p, scldpc::kMaxLdsBytes, &a.lay))
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                 "scldpc_full_bp_device: nk=%d CN words + n=%d VN bits do not fit 160 KiB of LDS", nk, n);
+    bool global_ws = false;
+    if (!packed && make_layout<Wide>(p, scldpc::kMaxLdsBytes, &a.lay)) {
+        // CN words to a global workspace; the VN bitmap, scan bitmap and queues must still fit the LDS
+        if (make_layout<WideG>(p, scldpc::kMaxLdsBytes, &a.lay))
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                     "scldpc_full_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
+        global_ws = true;
+        void *ws = nullptr;
+        if (int rc = scldpc::workspace((size_t)ntrials * nk * sizeof(uint32_t), &ws)) return rc;
+        a.ws = static_cast<uint32_t *>(ws);
+    }
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.cn_lim = is_term ? nk : p->L * p->cns_pos;                    // BPT:944-948
     a.max_it = max_it; a.rows_cap = traj ? rows_cap : 0;
@@ -448,6 +476,7 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
 #define PICK(ST, TRAJ, BLK) (d4 ? (adj16 ? full_bp_kernel<ST, TRAJ, 4, true, BLK> : full_bp_kernel<ST, TRAJ, 4, false, BLK>) \
                                 : (adj16 ? full_bp_kernel<ST, TRAJ, 0, true, BLK> : full_bp_kernel<ST, TRAJ, 0, false, BLK>))
     if (packed) { block = 512; kern = PICK(Packed, false, 512); }
+    else if (global_ws) kern = traj ? PICK(WideG, true, 1024) : PICK(WideG, false, 1024);
     else if (traj) kern = PICK(Wide, true, 1024);
     else kern = PICK(Wide, false, 1024);
 #undef PICK

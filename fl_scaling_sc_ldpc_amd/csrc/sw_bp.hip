@@ -33,16 +33,24 @@ struct Args {
     int dv, L, vns_pos, cns_pos, n, nk, W, max_it, init_it;
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
+    uint32_t *ws;                   // [T][nk] CN words in global memory (G only)
     const uint32_t *chan;
     int32_t *counters;
     uint32_t *erased_out;
 };
 
-template <int DV, bool A16>
+// G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. L=100, N=2000) instead of LDS
+template <int DV, bool A16, bool G>
 __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *cn_state = lds + a.lay.cn_state;
+    uint32_t *cn_state;
+    if constexpr (G) cn_state = a.ws + (size_t)blockIdx.x * a.nk;
+    else             cn_state = lds + a.lay.cn_state;
+    auto ldw = [&](int c) -> uint32_t {      // reads past the CU's L1 when the words live in global memory
+        if constexpr (G) return __hip_atomic_load(&cn_state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else             return cn_state[c];
+    };
     uint32_t *S = lds + a.lay.S;
     uint32_t *fbits = lds + a.lay.fbits;
     uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             int *rem_cnt = &scal[S_REM + gen % 3];
             int removed = 0;
             auto release = [&](uint32_t c) {
-                const uint32_t w = cn_state[c];
+                const uint32_t w = ldw(c);
                 if ((w >> kCntShift) != 1u) return;                         // its VN went via another CN this round
                 const uint32_t j = w & kSumMask;
                 if ((int)j < jlo) return;                                   // frozen VN: stays erased for good
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
                 // promote CNs into the round's own frontier
                 for (int base = c0 & ~63; base < c1; base += kBlock) {
                     const int c = base + tid;
-                    const bool v = c >= c0 && c < c1 && (cn_state[c] >> kCntShift) == 1u;
+                    const bool v = c >= c0 && c < c1 && (ldw(c) >> kCntShift) == 1u;
                     const unsigned long long m = __ballot(v);
                     if (c - lane < c1) {
                         if (lane == 0) fbits[c >> 5] = (uint32_t)m;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             bool pair = true;
             uint32_t partner = 0;
             for (int i = 0; i < dv; i++) {
-                const uint32_t s = cn_state[cc[i]];
+                const uint32_t s = ldw(cc[i]);
                 const uint32_t b2 = (s & kSumMask) - (uint32_t)va;
                 if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
                 partner = b2;
@@ -220,13 +228,13 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
     }
 }
 
-int make_layout(const scldpc_code_params *p, int W, Layout *lay)
+int make_layout(const scldpc_code_params *p, int W, bool global_ws, Layout *lay)
 {
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
     lay->nw = (n + 31) / 32;
-    lay->cn_state = take(nk);
+    lay->cn_state = take(global_ws ? 0 : nk);
     lay->S = take(lay->nw);
     lay->fbits = take(((nk + 63) / 64) * 2);
     lay->pos_cnt = take(p->L);
@@ -260,15 +268,25 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
     Args a{};
-    if (make_layout(p, W, &a.lay))
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                 "scldpc_sw_bp_device: nk=%d CN words + n=%d VN bits do not fit 160 KiB of LDS", nk, n);
+    bool gws = false;
+    if (make_layout(p, W, false, &a.lay)) {
+        if (make_layout(p, W, true, &a.lay))
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                     "scldpc_sw_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
+        gws = true;
+        void *ws = nullptr;
+        if (int rc = scldpc::workspace((size_t)ntrials * nk * sizeof(uint32_t), &ws)) return rc;
+        a.ws = static_cast<uint32_t *>(ws);
+    }
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.W = W; a.max_it = max_it; a.init_it = init_it ? init_it : max_it;     // BPW:2101-2102
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
 
-    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true> : sw_bp_kernel<4, false>)
-                                          : (adj16 ? sw_bp_kernel<0, true> : sw_bp_kernel<0, false>);
+    void (*kern)(const Args);
+    if (gws) kern = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true, true> : sw_bp_kernel<4, false, true>)
+                               : (adj16 ? sw_bp_kernel<0, true, true> : sw_bp_kernel<0, false, true>);
+    else     kern = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true, false> : sw_bp_kernel<4, false, false>)
+                               : (adj16 ? sw_bp_kernel<0, true, false> : sw_bp_kernel<0, false, false>);
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

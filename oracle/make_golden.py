@@ -64,6 +64,10 @@ SETS += [
     ("c2_bpt_M500_L50_e460_trunc", "bpt", 500, 50, 8, 6000, 0.46, dict(is_term=0)),
     ("c2_bpw_M500_L50_e465_W20_it6_init60", "bpw", 500, 50, 8, 7000, 0.465, dict(W=20, max_it=6, init_it=60)),
     ("c2_bpw_M500_L50_e470_W10_it20", "bpw", 500, 50, 6, 8000, 0.47, dict(W=10, max_it=20, init_it=0)),
+    # bp_traj's shipped size (Def_M = 2500, BPT:25) and BASELINE config 4 (L=100, N=2000): beyond the LDS-resident kernels
+    ("c3_bpt_M2500_L50_e460_trunc", "bpt", 2500, 50, 2, 9000, 0.46, dict(is_term=0)),
+    ("c3_bpt_M2500_L50_e470_term", "bpt", 2500, 50, 2, 9100, 0.47, dict(is_term=1)),
+    ("c4_bpw_M1000_L100_e470_W10_it20", "bpw", 1000, 100, 3, 9200, 0.47, dict(W=10, max_it=20, init_it=0)),
     # whole-run replay: no re-seeding between frames, perm_code and RNG stream carry over (BPF:2117-2144)
     ("c2_bpf_M500_L50_e480_wholerun", "bpf", 500, 50, 6, 7, 0.48, dict(whole_run=True)),
     ("tiny_bpf_M5_L10_e480_wholerun", "bpf", 5, 10, 200, 7, 0.48, dict(whole_run=True)),

@@ -48,8 +48,10 @@ def test_error_paths_without_device(L):
     assert b"must equal" in L.scldpc_last_error()
     ok = _lib.CodeParams(4, 8, 50, 500, 1000)
     assert L.scldpc_full_bp_lds_bytes(C.byref(ok)) <= 160 * 1024
-    big = _lib.CodeParams(4, 8, 50, 5000, 10000)           # N = 10000: CN words alone exceed the LDS
-    assert L.scldpc_full_bp_lds_bytes(C.byref(big)) > 160 * 1024
+    big = _lib.CodeParams(4, 8, 50, 5000, 10000)           # N = 10000: CN words go to the global workspace, bitmaps still fit
+    assert L.scldpc_full_bp_lds_bytes(C.byref(big)) <= 160 * 1024
+    huge = _lib.CodeParams(4, 8, 50, 50000, 100000)        # N = 100000: even the VN bitmap exceeds the LDS
+    assert L.scldpc_full_bp_lds_bytes(C.byref(huge)) > 160 * 1024
     assert L.scldpc_full_bp_device(C.byref(ok), -1, None, None, 0, 1, None, None, 0, None, None) == -1
     assert L.scldpc_full_bp_device(C.byref(ok), 0, None, None, 0, 1, None, None, 0, None, None) == 0    # empty batch
     assert L.scldpc_full_bp_device(C.byref(ok), 1, None, None, 0, 1, None, None, 0, None, None) == -1   # null buffers

@@ -220,8 +220,8 @@ def test_edge_cases(E, oracle):
                                      res["num_blocks_err_exp"]] and c[t, 5] == res["iterations"]
         assert res["num_erasures"] < p.n
     # ragged n (not a multiple of 32) is covered by (9,24) above; ensembles beyond the LDS budget are refused
-    big = E.make_params(4, 8, 50, 10000)
-    with pytest.raises(E.ScldpcError, match="160 KiB"):
+    big = E.make_params(4, 8, 50, 100000)
+    with pytest.raises(E.ScldpcError, match="2\\^24|160 KiB"):
         E.full_bp(big, torch.empty((1, big.n, 4), dtype=torch.int32, device="cuda"),
                   torch.empty((1, big.nw), dtype=torch.int32, device="cuda"))
 
@@ -264,3 +264,42 @@ def test_compact_adjacency_is_equivalent(E, L, N, eps):
         s32 = E.sw_bp(p, a32, c32, 5, 4, 9, want_erased=True)
         s16 = E.sw_bp(p, a16, c16, 5, 4, 9, want_erased=True)
         assert (s32["counters"] == s16["counters"]).all() and (s32["erased"] == s16["erased"]).all()
+
+
+@pytest.mark.parametrize("L,N,eps", [(50, 5000, 0.47), (50, 10000, 0.46), (100, 2000, 0.47)])
+def test_ensembles_beyond_the_lds_use_the_global_workspace(E, oracle, L, N, eps):
+    """bp_traj's shipped size (N=5000), the notebook's peeling size (N=10000) and BASELINE config 4 (L=100, N=2000):
+    the CN words move to a global-memory workspace; results stay bit-exact (rows included)."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    T = 3
+    d_adj, d_ch = E.sample_philox(p, 5, 0, T, eps, adj16=(N <= 5000)) if p.cns_pos * 8 <= 8192 else (None, None)
+    if d_adj is None:                       # the device sampler ranks up to 8192 sockets per position: sample on the host
+        adj, ch = E.sample_glibc_trials(p, [11, 12, 13], eps)
+        d_adj, d_ch = E.to_device(adj, ch)
+    A = d_adj.cpu().numpy()
+    if A.dtype == np.int16:
+        A = E.adj16_to_global(p, A)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n)
+    out = E.full_bp(p, d_adj, d_ch, rows_cap=4096, want_erased=True)
+    lim = E.full_bp(p, d_adj, d_ch, max_it=25, is_term=False)
+    torch.cuda.synchronize()
+    c, rows = out["counters"].cpu().numpy(), out["rows"].cpu().numpy()
+    for t in range(T):
+        g = oracle.Graph.from_vn_adj(po, A[t])
+        res, erased, orows = oracle.decode_bp(g, bits[t], literal=False, rows_cap=4096)
+        assert c[t, :4].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                     res["num_blocks_err_exp"]] and c[t, 5] == res["iterations"]
+        k = res["iterations"]
+        assert (rows[t, :k, 0] == orows["deg1"]).all() and (rows[t, :k, 1] == orows["recovered"]).all() \
+            and (rows[t, :k, 2] == orows["first_pos"]).all()
+        assert (E.unpack_bits(out["erased"][t].cpu().numpy(), p.n) == erased).all()
+        res2, _, _ = oracle.decode_bp(g, bits[t], max_it=25, is_term=0, literal=False)
+        assert lim["counters"][t, :4].tolist() == [res2["num_erasures"], res2["num_blocks_err"],
+                                                   res2["num_erasures_exp"], res2["num_blocks_err_exp"]]
+    sw = E.sw_bp(p, d_adj, d_ch, 10, 20, 0)["counters"].cpu().numpy()
+    for t in range(T):
+        res, _ = oracle.decode_sw(oracle.Graph.from_vn_adj(po, A[t]), bits[t], 10, 20, 0, literal=False)
+        assert sw[t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                      res["num_blocks_err_exp"], res["num_erasures_p1"]]

@@ -39,7 +39,7 @@ def test_oracle_small(oracle, name):
     _check(oracle, g, DEC[g.variant])
 
 
-@pytest.mark.parametrize("name", golden_names(prefixes=("c2_",)))
+@pytest.mark.parametrize("name", golden_names(prefixes=("c2_", "c3_", "c4_")))
 def test_oracle_config_size(oracle, name):
     """(4,8), L=50, N=1000 — the BASELINE.json ensemble.  The literal decoder on a third of the trials
     (≈0.25 s each), the peeling model on all of them."""
