@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trials per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
     ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")
     a = ap.parse_args()
 
@@ -112,28 +113,44 @@ def main():
     from fl_scaling_sc_ldpc_amd import engine as E
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch
-    d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int32 if a.adj32 else torch.int16, device=dev)
-    d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
-    d_cnt = torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev)
+    # Two (adjacency, channel, counters) buffers and two streams: the sampler of step k+1 runs beside the decoder of
+    # step k (the first is LDS/VALU-heavy, the second waits on memory most of the time, so they share a CU well).
+    nbuf = 1 if a.no_overlap else 2
+    d_adj = [torch.empty((B, p.n, p.dv), dtype=torch.int32 if a.adj32 else torch.int16, device=dev) for _ in range(nbuf)]
+    d_ch = [torch.empty((B, p.nw), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_cnt = [torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     run = E.new_run(dev)
     seed = 20261004
+    s_dec = torch.cuda.current_stream(dev)
+    s_samp = s_dec if a.no_overlap else torch.cuda.Stream(dev)
+    sampled = [torch.cuda.Event() for _ in range(nbuf)]
+    decoded = [torch.cuda.Event() for _ in range(nbuf)]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+           torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
     def step(k, timed_idx=None):
         # global trial index: step-major, then rank — disjoint ranges on every rank
         trial0 = (k * world + rank) * B
+        b = k % nbuf
         e = ev[timed_idx] if timed_idx is not None else None
-        if e:
-            e[0].record()
-        E.sample_philox(p, seed, trial0, B, EPS, out=(d_adj, d_ch))
-        if e:
-            e[1].record()
-        E.full_bp(p, d_adj, d_ch, counters=d_cnt)
-        if e:
-            e[2].record()
-        E.accumulate_run(d_cnt, run, 0)
+        with torch.cuda.stream(s_samp):
+            s_samp.wait_event(decoded[b])                   # buffer b is free once its previous decode has finished
+            if e:
+                e[0].record(s_samp)
+            E.sample_philox(p, seed, trial0, B, EPS, out=(d_adj[b], d_ch[b]))
+            if e:
+                e[1].record(s_samp)
+            sampled[b].record(s_samp)
+        with torch.cuda.stream(s_dec):
+            s_dec.wait_event(sampled[b])
+            if e:
+                e[2].record(s_dec)
+            E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
+            if e:
+                e[3].record(s_dec)
+            E.accumulate_run(d_cnt[b], run, 0)
+            decoded[b].record(s_dec)
 
     def fence():
         torch.cuda.synchronize()
@@ -162,7 +179,7 @@ def main():
 
     if rank == 0:
         ms_sample = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
-        ms_bp = sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps
+        ms_bp = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
         E_edges = p.n * p.dv
         b_alg = 16 * E_edges + p.n // 8
         achieved = b_alg * B / (ms_bp * 1e-3) / 1e9
@@ -175,7 +192,8 @@ def main():
             "config": {"workload": workload_name(), "trials_per_gpu_per_step": B,
                        "step": "device sample (code+channel) -> decodeBP -> plr_computation",
                        "rng": "philox4x32-10 keyed by (seed, trial)",
-                       "adjacency": "int32 global ids" if a.adj32 else "uint16 position-local ids", "parallelism": f"trial-sharded x{world}"},
+                       "adjacency": "int32 global ids" if a.adj32 else "uint16 position-local ids", "parallelism": f"trial-sharded x{world}",
+                       "streams": "sampler(k+1) || decoder(k), double-buffered" if nbuf == 2 else "single stream"},
             "roofline": {"bound": "hbm", "kernel": "full_bp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_trial": b_alg, "trials_per_launch": B, "ms_per_launch": ms_bp},

@@ -92,7 +92,7 @@ def lib():
     L.scldpc_sw_bp_device_adj16.argtypes = L.scldpc_sw_bp_device.argtypes
     L.scldpc_peel_sweep_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.scldpc_peel_sweep_device_adj16.argtypes = L.scldpc_peel_sweep_device.argtypes
-    L.scldpc_peel_pick_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, u64, u64, vp, vp, vp]
+    L.scldpc_peel_pick_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, u64, u64, vp, vp, vp, vp]
     L.scldpc_peel_pick_device_adj16.argtypes = L.scldpc_peel_pick_device.argtypes
     L.scldpc_r1_moments_device.argtypes = [i32, i32, vp, vp, vp]
     L.scldpc_accumulate_run_device.argtypes = [i32, vp, i64, vp, vp]

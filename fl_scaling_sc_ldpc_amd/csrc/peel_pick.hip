@@ -27,9 +27,11 @@ struct Args {
     int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
     uint32_t magic_v, seed_lo, seed_hi;
     unsigned long long trial0;
-    int off_d1, off_mt, off_u, off_sc;   // LDS offsets (32-bit words) behind the CN words
+    int off_d1, off_blk, off_mt, off_u, off_sc;   // LDS offsets (32-bit words) behind the CN words
     const void *vn_adj;
     const uint32_t *chan;
+    uint32_t *ws;                   // [T][ncn] CN words in global memory (G only)
+    unsigned long long *moments;    // optional [3][steps+1]: #(r1 != 0), Σ r1, Σ r1² over the trials (atomic adds)
     uint32_t *mt;                   // [T][625]: 624 state words + index
     int32_t *r1;                    // [T][steps+1] or null
     int32_t *out;                   // [T][4]: #erased, #picked, last r1, steps executed with a pick
@@ -48,11 +50,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-template <int DV, bool A16>
+// G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. the notebook's N = 10000)
+template <int DV, bool A16, bool G>
 __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *cn = lds;                                                   // ncn words
+    uint32_t *cn;                                                         // ncn words
+    if constexpr (G) cn = a.ws + (size_t)blockIdx.x * a.ncn;
+    else             cn = lds;
+    auto ldw = [&](int c) -> uint32_t {
+        if constexpr (G) return __hip_atomic_load(&cn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else             return cn[c];
+    };
+    int *blk = reinterpret_cast<int *>(lds + a.off_blk);                  // #degree-1 CNs per block of 64 bitmap words
     unsigned long long *d1 = reinterpret_cast<unsigned long long *>(lds + a.off_d1);   // nd1 words of 64 bits
     uint32_t *mt = lds + a.off_mt;                                        // 624 words
     uint32_t *U = lds + a.off_u;                                          // channel bits (build only)
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
     for (int c = tid; c < a.ncn; c += kBlock) cn[c] = 0;
     for (int w = tid; w < a.nd1; w += kBlock) d1[w] = 0ull;
     if (tid == 0) { sc[0] = 0; sc[1] = 0; }
+    if (tid < 64) blk[tid] = 0;
     int ne_local = 0;
     for (int w = tid; w < a.nw; w += kBlock) {
         uint32_t x = a.chan[(size_t)trial * a.nw + w];
@@ -93,9 +104,9 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
     int n1_local = 0;
     for (int base = 0; base < ts; base += kBlock) {
         const int c = base + tid;
-        const bool one = c < ts && (cn[c] >> kCntShift) == 1u;
+        const bool one = c < ts && (ldw(c) >> kCntShift) == 1u;
         const unsigned long long m = __ballot(one);
-        if (lane == 0 && c < ts) d1[c >> 6] = m;
+        if (lane == 0 && c < ts) { d1[c >> 6] = m; if (m) atomicAdd(&blk[c >> 12], __popcll(m)); }
         n1_local += one;
     }
     {
@@ -107,10 +118,16 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
 
     int n1 = sc[1], picked = 0, with_pick = 0;
     int32_t *r1 = a.r1 ? a.r1 + (size_t)trial * (a.steps + 1) : nullptr;
-    if (r1 && lane == 0) r1[0] = n1;
+    if (lane == 0) {
+        if (r1) r1[0] = n1;
+        if (a.moments && n1) {
+            atomicAdd(&a.moments[0], 1ull);
+            atomicAdd(&a.moments[(size_t)(a.steps + 1)], (unsigned long long)n1);
+            atomicAdd(&a.moments[2 * (size_t)(a.steps + 1)], (unsigned long long)n1 * (unsigned long long)n1);
+        }
+    }
     uint32_t mti = a.rng_mode == 0 ? a.mt[(size_t)trial * 625 + 624] : 0u;      // MT index, or Philox draw counter
     const unsigned long long gtrial = a.trial0 + (unsigned long long)trial;
-    const int wpl = (a.nd1 + 63) / 64;         // bitmap words per lane for the rank-select
 
     auto next_u32 = [&]() -> uint32_t {        // wave-uniform result
         if (a.rng_mode == 0) {
@@ -146,50 +163,51 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         const int k = 32 - __clz(n1);
         uint32_t x;
         do { x = next_u32() >> (32 - k); } while (x >= (uint32_t)n1);
-        // ---- m = x-th set bit of the degree-1 bitmap, ascending ---------------------------------
-        uint32_t cl = 0;
-        for (int w = 0; w < wpl; w++) {
-            const int idx = lane * wpl + w;
-            cl += idx < a.nd1 ? (uint32_t)__popcll(d1[idx]) : 0u;
-        }
-        const uint32_t incl = wave_inclusive_scan(cl);
-        const unsigned long long hit = __ballot(incl > x);
-        const int L0 = __ffsll((long long)hit) - 1;
-        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cl), L0);
+        // ---- m = x-th set bit of the degree-1 bitmap, ascending: block of 64 words, word, bit ------------
+        const uint32_t bc = (uint32_t)blk[lane];
+        const uint32_t binc = wave_inclusive_scan(bc);
+        const int B0 = __ffsll((long long)__ballot(binc > x)) - 1;
+        uint32_t r = x - (uint32_t)__builtin_amdgcn_readlane((int)(binc - bc), B0);
+        const int widx = B0 * 64 + lane;
+        const unsigned long long word = widx < a.nd1 ? d1[widx] : 0ull;
+        const uint32_t wc = (uint32_t)__popcll(word);
+        const uint32_t winc = wave_inclusive_scan(wc);
+        const int W0 = __ffsll((long long)__ballot(winc > r)) - 1;
+        r -= (uint32_t)__builtin_amdgcn_readlane((int)(winc - wc), W0);
         int m = -1;
-        if (lane == L0) {
-            uint32_t r = x - before;
-            for (int w = 0; w < wpl; w++) {
-                unsigned long long word = d1[lane * wpl + w];
-                const uint32_t pc = (uint32_t)__popcll(word);
-                if (r < pc) {
-                    while (r--) word &= word - 1;
-                    m = (lane * wpl + w) * 64 + (__ffsll((long long)word) - 1);
-                    break;
-                }
-                r -= pc;
-            }
+        if (lane == W0) {
+            unsigned long long w = word;
+            while (r--) w &= w - 1;
+            m = widx * 64 + (__ffsll((long long)w) - 1);
         }
-        m = __builtin_amdgcn_readlane(m, L0);
+        m = __builtin_amdgcn_readlane(m, W0);
         // ---- remove its single VN from all its CNs (PD:769-777) ------------------------------------
-        const int j = (int)(cn[m] & kSumMask);
+        const int j = (int)(ldw(m) & kSumMask);
         int32_t cc[8];
         load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
         bool plus = false, minus = false;
         if (lane < dv) {
             const int c = cc[lane];
-            const uint32_t w = cn[c] - (kCntOne + (uint32_t)j);
-            cn[c] = w;
-            const uint32_t nc = w >> kCntShift;
+            const uint32_t nc = (atomicSub(&cn[c], kCntOne + (uint32_t)j) >> kCntShift) - 1u;
             if (c < ts) {
                 minus = nc == 0u;                       // was 1
                 plus = nc == 1u;                        // became 1
-                if (plus || minus) atomicXor(&d1[c >> 6], 1ull << (c & 63));
+                if (plus || minus) {
+                    atomicXor(&d1[c >> 6], 1ull << (c & 63));
+                    atomicAdd(&blk[c >> 12], plus ? 1 : -1);
+                }
             }
         }
         n1 += __popcll(__ballot(plus)) - __popcll(__ballot(minus));
         picked++; with_pick++;
-        if (r1 && lane == 0) r1[s + 1] = n1;
+        if (lane == 0) {
+            if (r1) r1[s + 1] = n1;
+            if (a.moments && n1) {
+                atomicAdd(&a.moments[s + 1], 1ull);
+                atomicAdd(&a.moments[(size_t)(a.steps + 1) + s + 1], (unsigned long long)n1);
+                atomicAdd(&a.moments[2 * (size_t)(a.steps + 1) + s + 1], (unsigned long long)n1 * (unsigned long long)n1);
+            }
+        }
     }
     // no degree-1 CN left: the count (0) is copied forward, nothing is drawn (PD:765-767)
     if (r1)
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
 static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
                             const uint32_t *d_chan_bits, int32_t total_size, int32_t num_steps,
                             uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                            int32_t *d_r1, int32_t *d_out, void *stream)
+                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
     if (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits)))
@@ -231,18 +249,37 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
         if (((x0 * a.magic_v) >> 32) != (uint64_t)q || ((x1 * a.magic_v) >> 32) != x1 / (uint64_t)p->vns_pos)
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: reciprocal division inexact");
     }
-    int off = (ncn + 3) & ~3;
-    a.off_d1 = off; off += (2 * a.nd1 + 3) & ~3;
-    a.off_mt = off; off += 624;
-    a.off_u = off;  off += (a.nw + 3) & ~3;
-    a.off_sc = off; off += 4;
-    const size_t lds_bytes = 4u * (size_t)off;
-    if (lds_bytes + 64 > (size_t)scldpc::kMaxLdsBytes)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                 "scldpc_peel_pick_device: %d CN words + bitmaps do not fit 160 KiB of LDS", ncn);
+    if (a.nd1 > 4096)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: more than 262144 pickable CNs");
+    bool gws = false;
+    size_t lds_bytes = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        gws = pass == 1;
+        int off = gws ? 0 : (ncn + 3) & ~3;
+        a.off_d1 = off; off += (2 * a.nd1 + 3) & ~3;
+        a.off_blk = off; off += 64;
+        a.off_mt = off; off += 624;
+        a.off_u = off;  off += (a.nw + 3) & ~3;
+        a.off_sc = off; off += 4;
+        lds_bytes = 4u * (size_t)off;
+        // keep a few trials per CU in flight when the CN words are in the workspace
+        if (lds_bytes + 64 <= (size_t)scldpc::kMaxLdsBytes) break;
+        if (gws)
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                     "scldpc_peel_pick_device: bitmaps of %d CNs / %d VNs do not fit 160 KiB of LDS", ncn, n);
+    }
+    if (gws) {
+        void *ws = nullptr;
+        if (int rc = scldpc::workspace((size_t)ntrials * ncn * sizeof(uint32_t), &ws)) return rc;
+        a.ws = static_cast<uint32_t *>(ws);
+    }
+    a.moments = reinterpret_cast<unsigned long long *>(d_moments);
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.mt = d_mt_state; a.r1 = d_r1; a.out = d_out;
-    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true> : peel_pick_kernel<4, false>)
-                                          : (adj16 ? peel_pick_kernel<0, true> : peel_pick_kernel<0, false>);
+    void (*kern)(const Args);
+    if (gws) kern = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true, true> : peel_pick_kernel<4, false, true>)
+                               : (adj16 ? peel_pick_kernel<0, true, true> : peel_pick_kernel<0, false, true>);
+    else     kern = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true, false> : peel_pick_kernel<4, false, false>)
+                               : (adj16 ? peel_pick_kernel<0, true, false> : peel_pick_kernel<0, false, false>);
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
@@ -254,18 +291,18 @@ extern "C" int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntri
                                        const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                        int32_t total_size, int32_t num_steps,
                                        uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                       int32_t *d_r1, int32_t *d_out, void *stream)
+                                       int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
 {
     return launch_peel_pick(p, ntrials, d_vn_adj, false, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
-                            d_r1, d_out, stream);
+                            d_r1, d_moments, d_out, stream);
 }
 
 extern "C" int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                              const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                              int32_t total_size, int32_t num_steps,
                                              uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                             int32_t *d_r1, int32_t *d_out, void *stream)
+                                             int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
 {
     return launch_peel_pick(p, ntrials, d_vn_adj16, true, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
-                            d_r1, d_out, stream);
+                            d_r1, d_moments, d_out, stream);
 }

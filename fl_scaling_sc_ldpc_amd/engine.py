@@ -215,7 +215,7 @@ def peel_sweep(p, d_adj, d_chan, total_size, sweep_start=0, lost_lo=0, lost_hi=N
     return {"out": out, "lost": lost}
 
 
-def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, trial0=0, want_r1=True):
+def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, trial0=0, want_r1=True, moments=None):
     """One trial of simulate_peeling_decoder_ldpc's loop body per batch entry (PD:750-785).
     mt_state: int32/uint32-as-int32 tensor [T,625] (CPython MT19937 state, updated in place) or None (Philox)."""
     _require_gpu()
@@ -229,8 +229,9 @@ def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, tr
     fn = lib().scldpc_peel_pick_device_adj16 if _is_adj16(d_adj) else lib().scldpc_peel_pick_device
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(total_size), int(num_steps),
              mt_state.data_ptr() if mt_state is not None else None, int(seed), int(trial0),
-             r1.data_ptr() if r1 is not None else None, out.data_ptr(), _stream_ptr(dev)))
-    return {"out": out, "r1": r1}
+             r1.data_ptr() if r1 is not None else None, moments.data_ptr() if moments is not None else None,
+             out.data_ptr(), _stream_ptr(dev)))
+    return {"out": out, "r1": r1, "moments": moments}
 
 
 def r1_moments(d_r1, moments=None):

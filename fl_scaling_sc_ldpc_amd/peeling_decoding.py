@@ -190,12 +190,13 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
     for done in range(0, num_repeats, batch):
         nb = min(batch, num_repeats - done)
         d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device, adj16=True)
-        res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done)
+        if want_moments and moments is None:
+            moments = torch.zeros((3, num_pd_steps + 1), dtype=torch.int64, device=device)
+        res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done,
+                          want_r1=not want_moments, moments=moments)
         o = res["out"].cpu().numpy()
         plrs[done:done + nb] = (o[:, 0] - o[:, 1]) / total_generated
-        if want_moments:
-            moments = E.r1_moments(res["r1"], moments)
-        else:
+        if not want_moments:
             r1_all[done:done + nb] = res["r1"].cpu().numpy()
     return None, (moments.cpu().numpy() if want_moments else r1_all), plrs
 

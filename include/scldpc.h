@@ -180,18 +180,20 @@ int scldpc_peel_sweep_device_adj16(const scldpc_code_params *p, int32_t ntrials,
  * as random.getstate() gives it); every pick draws `_randbelow(#degree-1 CNs)` from it exactly as
  * random.choice does (PD:1026) and the advanced state is written back, so a host loop can chain the trials of
  * one reference run.  d_mt_state == NULL ⇒ Philox4x32-10 keyed by (seed, trial0 + trial), same rejection rule.
- * d_r1 (optional) int32 [ntrials][num_steps+1] = r1[o, :] (PD:758,781).  d_out int32 [ntrials][4]:
- * #erased VNs, #picks, last r1 value, #steps that had a degree-1 CN. */
+ * d_r1 (optional) int32 [ntrials][num_steps+1] = r1[o, :] (PD:758,781).  d_moments (optional) int64
+ * [3][num_steps+1], accumulated in place over the trials of the call like scldpc_r1_moments_device — for runs
+ * whose trajectories are too large to keep (N = 10000: 1.2 MB per trial).  d_out int32 [ntrials][4]:
+ * #erased VNs, #picks, last r1 value, #steps that had a degree-1 CN.  At most 262144 pickable CNs. */
 int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntrials,
                             const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                             int32_t total_size, int32_t num_steps,
                             uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                            int32_t *d_r1, int32_t *d_out, void *stream);
+                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream);
 int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                   const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                   int32_t total_size, int32_t num_steps,
                                   uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                  int32_t *d_r1, int32_t *d_out, void *stream);
+                                  int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream);
 
 /* Integer moments of a batch of trajectories, the device half of main_simulate_variance (PD:1264-1294) /
  * calc_nu_chunk (fl_scaling/est_scaling_params.py:90-94,131-138): d_moments int64 [3][ncols], accumulated in

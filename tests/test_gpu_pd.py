@@ -176,3 +176,37 @@ def test_ber_sim_cli_writes_the_reference_rows(PD, tmp_path):
         assert row == " ".join(str(x) for x in exp)
     with pytest.raises(NotImplementedError):
         PD.simulate_sc_ldpc(0.4, 4, 8, 10, 20, True, True, True, False, 1)
+
+
+@pytest.mark.parametrize("L,M,e,term", [(50, 2000, 0.47, False), (20, 2000, 0.46, True), (60, 1000, 0.48, False)])
+def test_peel_pick_beyond_the_lds_budget(PD, oracle, L, M, e, term):
+    """CN words in the global workspace + two-level rank-select + in-kernel moments, against the CPU twin."""
+    from oracle import pd_oracle as P
+    E = PD.E
+    T = 3
+    none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=8)
+    none, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=8,
+                                                        want_moments=True, batch=2)
+    p = E.CodeParams(4, 8, L, M // 2, M)
+    d_adj, d_ch = E.sample_philox(p, 8, 0, T, e, adj16=True)
+    A = E.adj16_to_global(p, d_adj.cpu().numpy()).astype(np.int64)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n).astype(bool)
+    for t in range(T):
+        ref_r1, ref_plr = P.random_pick_trial(A[t], bits[t], 4, 8, L, M, e, term, P.PhiloxPickStream(8, t))
+        assert (r1[t] == ref_r1).all() and plrs[t] == ref_plr, (L, M, t)
+    assert (plrs2 == plrs).all()
+    assert (mom[0] == (r1 != 0).sum(0)).all() and (mom[1] == r1.sum(0)).all() and (mom[2] == (r1 ** 2).sum(0)).all()
+
+
+def test_peel_pick_notebook_size_exact_stream(PD):
+    """M = 10000 (the notebook's trajectory size, PD:1216) on a short chain, with the reference's own numpy + `random`
+    streams: the device consumes the MT19937 state exactly as random.choice would."""
+    from oracle import pd_oracle as P
+    np.random.seed(21); random.seed(21)
+    _, r1, plrs = PD.simulate_peeling_decoder_ldpc(0.47, 4, 8, 6, 10000, False, False, 1, [])
+    ref_r1, ref_plr = P.simulate_peeling_decoder_ldpc(21, 0.47, 4, 8, 6, 10000, False, 1)
+    assert (r1 == ref_r1).all() and (plrs == ref_plr).all()
+    assert random.random() == (lambda g: ([P.random_pick_trial(P.gen_slots(rs, 4, 8, 6, 10000),
+                                                                P.gen_erasures(rs, 0.47, 4, 8, 6, 10000), 4, 8, 6, 10000,
+                                                                0.47, False, g) for rs in [np.random.RandomState(21)]],
+                                          g.random())[1])(random.Random(21))
