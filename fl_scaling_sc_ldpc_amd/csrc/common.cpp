@@ -30,25 +30,26 @@ int check_params(const scldpc_code_params *p)
     return SCLDPC_OK;
 }
 
-static void *g_ws[16] = {nullptr};
-static size_t g_ws_bytes[16] = {0};
+static void *g_ws[16][2] = {{nullptr}};
+static size_t g_ws_bytes[16][2] = {{0}};
 
-int workspace(size_t bytes, void **out)
+int workspace(size_t bytes, void **out, int slot)
 {
     int dev = 0;
     SCLDPC_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return set_error(SCLDPC_ERR_BAD_ARG, "device ordinal %d out of range", dev);
-    if (bytes > g_ws_bytes[dev]) {
-        if (g_ws[dev]) {
+    if (dev < 0 || dev >= 16 || slot < 0 || slot > 1)
+        return set_error(SCLDPC_ERR_BAD_ARG, "device ordinal %d / workspace slot %d out of range", dev, slot);
+    if (bytes > g_ws_bytes[dev][slot]) {
+        if (g_ws[dev][slot]) {
             SCLDPC_HIP_CHECK(hipDeviceSynchronize());
-            SCLDPC_HIP_CHECK(hipFree(g_ws[dev]));
-            g_ws[dev] = nullptr; g_ws_bytes[dev] = 0;
+            SCLDPC_HIP_CHECK(hipFree(g_ws[dev][slot]));
+            g_ws[dev][slot] = nullptr; g_ws_bytes[dev][slot] = 0;
         }
         const size_t want = bytes + bytes / 4;
-        SCLDPC_HIP_CHECK(hipMalloc(&g_ws[dev], want));
-        g_ws_bytes[dev] = want;
+        SCLDPC_HIP_CHECK(hipMalloc(&g_ws[dev][slot], want));
+        g_ws_bytes[dev][slot] = want;
     }
-    *out = g_ws[dev];
+    *out = g_ws[dev][slot];
     return SCLDPC_OK;
 }
 

@@ -18,8 +18,9 @@ inline int nw_of(const scldpc_code_params *p) { return (n_of(p) + 31) / 32; }
 int check_params(const scldpc_code_params *p);
 
 // Library-owned device scratch (CN words of ensembles beyond the LDS budget): one allocation per process and
-// device, grown on demand (never inside a stream capture: a growth synchronises the device before freeing).
-int workspace(size_t bytes, void **out);
+// device and slot, grown on demand (never inside a stream capture: a growth synchronises the device before freeing).
+// slot 0: CN words of the decoders; slot 1: the big-ensemble sampler's scratch (the two may run on different streams).
+int workspace(size_t bytes, void **out, int slot = 0);
 
 constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 

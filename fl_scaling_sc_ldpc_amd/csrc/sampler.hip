@@ -234,6 +234,116 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
     STAMP_FLUSH();
 }
 
+// Large ensembles (more than 8192 sockets per position, e.g. N = 5000 / 10000): same keys, same ranking, but the
+// per-socket scratch (keys, arrival slots, grouped keys, the ring of dv permutations) lives in a per-trial slice of
+// the library workspace (L2-resident) instead of LDS / registers; only the bucket counters stay in LDS.
+struct BigScratch { uint32_t *tk, *gkey; uint16_t *tslot, *gidx, *win; };
+
+template <int ROWS, bool ADJ16>
+__global__ __launch_bounds__(kThreads) void sample_philox_big_kernel(const SArgs a, char *ws, size_t ws_stride)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds;
+    uint32_t *wsum = lds + a.off_wsum;
+    uint32_t *wpre = wsum + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long trial = a.trial0 + blockIdx.x;
+    const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
+    const int S = a.S, nb = a.nb, dv = a.dv, ncalls = (S + 3) >> 2;
+    char *base = ws + (size_t)blockIdx.x * ws_stride;
+    uint32_t *tk = reinterpret_cast<uint32_t *>(base);
+    uint32_t *gkey = tk + S;
+    uint16_t *tslot = reinterpret_cast<uint16_t *>(gkey + S);
+    uint16_t *gidx = tslot + S;
+    uint16_t *win = gidx + S;                                       // dv * S
+
+    for (int p = 0; p < a.D; p++) {
+        for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
+        __syncthreads();
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s < S) { tk[s] = r[u]; tslot[s] = (uint16_t)atomicAdd(&hist[r[u] >> a.shift], 1u); }
+            }
+        }
+        __syncthreads();
+        {
+            const int b0 = wave * (ROWS * 64) + lane;
+            uint32_t v[ROWS], inc[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) v[r] = hist[b0 + r * 64];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                hist[b0 + r * 64] = carry + inc[r] - v[r];
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
+            }
+            if (lane == 0) wsum[wave] = carry;
+        }
+        __syncthreads();
+        {
+            const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t inc = wave_inclusive_scan(t);
+            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
+        }
+        auto bucket_base = [&](uint32_t b) -> uint32_t {
+            return b >= (uint32_t)nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
+        };
+        for (int s = tid; s < S; s += kThreads) {
+            const uint32_t k = tk[s], g = bucket_base(k >> a.shift) + tslot[s];
+            gkey[g] = k; gidx[g] = (uint16_t)s;
+        }
+        __syncthreads();
+        uint16_t *wp = win + (size_t)(p % dv) * S;
+        for (int s = tid; s < S; s += kThreads) {
+            const uint32_t k = tk[s], b = k >> a.shift;
+            const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1), self = g0 + tslot[s];
+            uint32_t rank = g0;
+            for (uint32_t g = g0; g < g1; g++) {
+                if (g == self) continue;
+                const uint32_t k2 = gkey[g];
+                rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+            }
+            wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
+        }
+        __syncthreads();
+        const int qpos = p - (dv - 1);
+        if (qpos >= 0) {
+            for (int t = tid; t < a.vns_pos; t += kThreads) {
+                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
+                for (int i = 0; i < dv; i++) {
+                    const uint32_t l = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                    if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l;
+                    else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l;
+                }
+            }
+        }
+    }
+    uint32_t *chan = a.chan + (size_t)blockIdx.x * a.nw;
+    for (int w = tid; w < a.nw; w += kThreads) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(w * 8 + c), 0x80000000u, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) word |= (uint32_t)((r[u] >> 1) < a.thresh) << (c * 4 + u);
+        }
+        const int j0 = w * 32;
+        if (j0 + 32 > a.n) word &= (1u << (a.n - j0)) - 1u;
+        for (int d = 0; d < a.ndoped; d++) {
+            const int lo = max(a.doped[d] * a.vns_pos, j0) - j0, hi = min((a.doped[d] + 1) * a.vns_pos, j0 + 32) - j0;
+            if (lo < hi) word &= ~(((hi - lo) == 32 ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << lo);
+        }
+        chan[w] = word;
+    }
+}
+
 template <bool ADJ16>
 int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials, double eps,
            int32_t ndoped, const int32_t *doped_positions, void *d_adj, uint32_t *d_chan_bits, void *stream,
@@ -251,12 +361,13 @@ int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t 
     SArgs a{};
     a.dv = p->dv; a.dc = p->dc; a.L = p->L; a.cns_pos = p->cns_pos; a.vns_pos = p->vns_pos;
     a.n = scldpc::n_of(p); a.S = p->cns_pos * p->dc; a.D = p->L + p->dv - 1; a.nw = scldpc::nw_of(p);
-    if (a.S > 8192 || p->dv > 8)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %d sockets per position > 8192 (LDS-resident ranking)", who, a.S);
+    if (a.S > 65536 || p->dv > 8)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %d sockets per position > 65536", who, a.S);
+    const bool big = a.S > 8192;
     if (ADJ16 && p->cns_pos > 65536)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: position-local CN ids need cns_pos <= 65536", who);
-    int lg = 10;                                    // nb = power of two >= max(S, kThreads)
-    while ((1 << lg) < a.S) lg++;
+    int lg = 10;                                    // nb = power of two >= max(S, kThreads), at most 16384
+    while ((1 << lg) < a.S && lg < 14) lg++;
     a.nb = 1 << lg; a.shift = 32 - lg; a.lgchunk = lg - 4;            // 16 waves
     a.dc_shift = -1;
     for (int k = 0; k < 8; k++) if ((1 << k) == p->dc) a.dc_shift = k;
@@ -276,9 +387,11 @@ int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t 
         a.thresh = (uint32_t)c;
     }
     int off = (a.nb + 3) & ~3;
-    a.off_gkey = off; off += (a.S + 3) & ~3;
-    a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
-    a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
+    if (!big) {
+        a.off_gkey = off; off += (a.S + 3) & ~3;
+        a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
+        a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
+    }
     a.off_wsum = off; off += 32 + kWaves * kWaves;
     const size_t lds_bytes = 4u * (size_t)off;
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
@@ -287,6 +400,19 @@ int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t 
     a.vn_adj16 = ADJ16 ? static_cast<uint16_t *>(d_adj) : nullptr;
     a.chan = d_chan_bits;
 
+    if (big) {
+        const size_t stride = (((size_t)a.S * (12 + 2 * p->dv)) + 255) & ~(size_t)255;
+        void *ws = nullptr;
+        if (int rc = scldpc::workspace(stride * (size_t)ntrials, &ws, 1)) return rc;
+        void (*kb)(const SArgs, char *, size_t) = a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16>
+                                                                 : sample_philox_big_kernel<8, ADJ16>;
+        SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(kb, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a,
+                           static_cast<char *>(ws), stride);
+        SCLDPC_HIP_CHECK(hipGetLastError());
+        return SCLDPC_OK;
+    }
     const int kmax = ((a.S + 3) / 4 + kThreads - 1) / kThreads;     // 1 or 2
     const int rows = a.nb / kThreads;                               // 1, 2, 4 or 8 rows of 64 per wave
     void (*kern)(const SArgs) = nullptr;

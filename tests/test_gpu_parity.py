@@ -303,3 +303,22 @@ def test_ensembles_beyond_the_lds_use_the_global_workspace(E, oracle, L, N, eps)
         res, _ = oracle.decode_sw(oracle.Graph.from_vn_adj(po, A[t]), bits[t], 10, 20, 0, literal=False)
         assert sw[t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
                                       res["num_blocks_err_exp"], res["num_erasures_p1"]]
+
+
+@pytest.mark.parametrize("L,N,eps,doped", [(8, 5000, 0.47, ()), (6, 10000, 0.46, (2,)), (5, 16384, 0.5, ())])
+def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, L, N, eps, doped):
+    """More than 8192 sockets per position: the sampler's scratch moves to the workspace; same integers as the twin."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    T = 3
+    for adj16 in (False, True):
+        d_adj, d_ch = E.sample_philox(p, 2, 40, T, eps, doped, adj16=adj16)
+        torch.cuda.synchronize()
+        A = d_adj.cpu().numpy()
+        if adj16:
+            A = E.adj16_to_global(p, A)
+        Cb = d_ch.cpu().numpy().view(np.uint32)
+        for t in range(T):
+            a, c = oracle.sample_philox(po, 2, 40 + t, eps, doped)
+            assert (a == A[t]).all() and (c == Cb[t]).all(), (L, N, adj16, t)
