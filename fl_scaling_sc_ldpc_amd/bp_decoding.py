@@ -128,7 +128,9 @@ class Simulator:
 
     def _alloc(self):
         p, batch = self.p, self.batch
-        self.d_adj = torch.empty((batch, p.n, p.dv), dtype=torch.int32, device=self.device)
+        # compact 2-byte position-local ids for device-sampled codes; the reference's int32 VNdegree for host replays
+        adj_dtype = torch.int16 if (self.rng == "philox" and p.cns_pos <= 65536) else torch.int32
+        self.d_adj = torch.empty((batch, p.n, p.dv), dtype=adj_dtype, device=self.device)
         self.d_ch = torch.empty((batch, p.nw), dtype=torch.int32, device=self.device)
         self.d_cnt = torch.empty((batch, NCOUNTERS), dtype=torch.int32, device=self.device)
 
