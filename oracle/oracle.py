@@ -276,3 +276,53 @@ def parse_ref_output(txt):
             trials[-1]["erased"] = np.frombuffer(ln[7:].encode(), dtype=np.uint8) - ord("0")
         i += 1
     return hdr, trials, run
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming mode (oracle/scldpc_stream_oracle.c; reference: main_streaming, BPF:1934-2054)
+# ---------------------------------------------------------------------------------------------
+class Stream:
+    """One stream: circular buffer of p.L positions.  rng_mode 0 = glibc (the reference's draws), 1 = Philox twin of
+    the device kernel; decoder 0 = literal messages, 1 = node-level model."""
+    FIELDS = ("pos", "nep", "ne", "be", "ee", "bee", "gb", "gbl", "gbe", "gble")
+
+    def __init__(self, params, seed, eps, W, doped=(), rng_mode=0, decoder=0, sid=0):
+        L = lib()
+        L.orc_stream_new.restype = C.c_void_p
+        L.orc_stream_new.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_int,
+                                     C.c_int, C.POINTER(C.c_int)]
+        L.orc_stream_step.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.orc_stream_last_erased.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.orc_stream_free.argtypes = [C.c_void_p]
+        d = (C.c_int * max(1, len(doped)))(*doped)
+        self.params = params
+        self._h = L.orc_stream_new(C.byref(params), rng_mode, decoder, seed, sid, eps, W, len(doped), d)
+
+    def step(self):
+        out = (C.c_int32 * 10)()
+        lib().orc_stream_step(self._h, out)
+        return dict(zip(self.FIELDS, (int(x) for x in out)))
+
+    def last_erased(self):
+        buf = np.zeros(self.params.vns_pos, dtype=np.uint8)
+        ok = lib().orc_stream_last_erased(self._h, _p(buf, C.c_uint8))
+        return buf if ok else None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_stream_free(self._h)
+            self._h = None
+
+
+def run_ref_stream(M, L, P, seed, eps, W, doped=(), dump=False):
+    """Run oracle/_ref/ref_stream_M<M>_L<L>; returns list of per-position dicts (+ 'erased' when dumped)."""
+    cmd = [os.path.join(REF_DIR, f"ref_stream_M{M}_L{L}"), str(P), str(seed), repr(float(eps)), str(W),
+           "1" if dump else "0", str(len(doped))] + [str(d) for d in doped]
+    txt = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    out = []
+    for ln in txt.split("\n"):
+        if ln.startswith("POS "):
+            out.append({k: int(v) for k, v in (tok.split("=") for tok in ln.split()[1:])})
+        elif ln.startswith("ERASED "):
+            out[-1]["erased"] = np.frombuffer(ln[7:].encode(), dtype=np.uint8) - ord("0")
+    return out

@@ -1,0 +1,69 @@
+/*
+ * TEST INFRASTRUCTURE — deterministic driver around the reference's STREAMING mode
+ * (main_streaming / decodeBP_SW_circular, BPF:1403-1500, 1934-2054), which the shipped source compiles out
+ * (`#define CIRCULAR` / `#undef CIRCULAR`, BPF:33-34).  oracle/Makefile drops the #undef on a pipe and appends
+ * this text; nothing of the reference is written to disk.
+ *
+ * Replays the body of main_streaming for ONE ε with srandom(seed) and prints, per decoded position, the value
+ * decodeBP_SW_circular returned and the running counters (BPF:2015-2046).
+ *
+ * usage: ref_stream_* P seed eps W dump ndoped d0 d1 …      (P = positions to decode)
+ */
+#undef main
+#include <stdint.h>
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: %s P seed eps W dump ndoped [d0 ...]\n", argv[0]); return 2; }
+    int P = atoi(argv[1]);
+    unsigned seed = (unsigned)strtoul(argv[2], 0, 10);
+    double epsilon = atof(argv[3]);
+    int W = atoi(argv[4]);
+    int dump = atoi(argv[5]);
+    int num_doped = atoi(argv[6]);
+    int doped_positions[32] = {0};
+    for (int i = 0; i < num_doped && i < 32; i++) doped_positions[i] = atoi(argv[7 + i]);
+
+    int n, nk, L = Def_L, CNsPos = Def_CNsPos, VNsPos = Def_VNsPos; double r, ShLm;
+    initialize_variables(&n, &nk, L, &r, &ShLm);
+    sim = 0; inizio_sim();
+    srandom(seed);
+    printf("HDR dv=%d dc=%d L=%d CNsPos=%d VNsPos=%d n=%d nk=%d P=%d seed=%u eps=%.17g W=%d ndoped=%d",
+           Def_dv, Def_dc, L, CNsPos, VNsPos, n, nk, P, seed, epsilon, W, num_doped);
+    for (int i = 0; i < num_doped; i++) printf(" d%d=%d", i, doped_positions[i]);
+    printf("\n");
+
+    int num_erasures = 0, num_blocks_err = 0, num_erasures_exp = 0, num_blocks_err_exp = 0;
+    int num_bits_generated = 0, num_blocks_generated = 0, num_bits_generated_exp = 0, num_blocks_generated_exp = 0;
+    int stream_lag = L / 2;
+    initialize_arrays_circular(n, nk, L, CNsPos);
+    int gen_stream_pos = 0;
+    for (gen_stream_pos = 0; gen_stream_pos < stream_lag; gen_stream_pos++) {
+        generate_stream_pos(gen_stream_pos, L, epsilon, VNsPos, CNsPos, num_doped, doped_positions);
+        initialize_messages_circular(gen_stream_pos, L, VNsPos, CNsPos);
+    }
+    for (int pos = 0; pos < P; pos++) {
+        int pos_vn_decision = pos - dv + 1, pos_vn_decision_exp = pos - 2 * dv + 1;
+        if (pos_vn_decision >= 0 && !is_position_doped_streaming(pos_vn_decision, num_doped, doped_positions)) {
+            num_bits_generated += VNsPos; num_blocks_generated += 1;
+        }
+        if (pos_vn_decision_exp >= 0 && !is_position_doped_streaming(pos_vn_decision_exp, num_doped, doped_positions)) {
+            num_bits_generated_exp += VNsPos; num_blocks_generated_exp += 1;
+        }
+        int nep = decodeBP_SW_circular(pos, n, L, W, VNsPos, CNsPos, &num_blocks_err, &num_erasures_exp, &num_blocks_err_exp);
+        num_erasures += nep;
+        printf("POS pos=%d nep=%d ne=%d be=%d ee=%d bee=%d gb=%d gbl=%d gbe=%d gble=%d\n", pos, nep, num_erasures,
+               num_blocks_err, num_erasures_exp, num_blocks_err_exp, num_bits_generated, num_blocks_generated,
+               num_bits_generated_exp, num_blocks_generated_exp);
+        if (dump && pos_vn_decision >= 0) {
+            printf("ERASED ");
+            int s0 = (pos_vn_decision % L) * VNsPos;
+            for (int j = s0; j < s0 + VNsPos; j++) putchar('0' + VNerased[j]);
+            printf("\n");
+        }
+        generate_stream_pos(gen_stream_pos, L, epsilon, VNsPos, CNsPos, num_doped, doped_positions);
+        initialize_messages_circular(gen_stream_pos, L, VNsPos, CNsPos);
+        gen_stream_pos++;
+    }
+    return 0;
+}

@@ -1,0 +1,47 @@
+"""The streaming oracle (oracle/scldpc_stream_oracle.c: literal messages and the node-level model, glibc draws)
+against golden vectors from the REAL reference's streaming mode (tests/golden/stream_*.npz), and — where
+oracle/_ref exists — against the reference itself on fresh seeds."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "stream_*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_streaming_oracle_matches_reference_golden(oracle, path):
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    p = oracle.Params(4, 8, m["L"], m["Def_M"], 2 * m["Def_M"])
+    for dec in (0, 1):
+        if dec == 0 and m["Def_M"] >= 500 and m["P"] > 60:
+            P = 60                      # the literal decoder is slow at this size; the node model runs it all
+        else:
+            P = m["P"]
+        s = oracle.Stream(p, m["seed"], m["eps"], m["W"], m["doped"], rng_mode=0, decoder=dec)
+        for k in range(P):
+            o = s.step()
+            assert [o[f] for f in oracle.Stream.FIELDS] == z["rows"][k].tolist(), (path, dec, k)
+            if "erased" in z.files and o["pos"] >= 3:
+                assert (s.last_erased() == z["erased"][k]).all(), (path, dec, k)
+
+
+def test_streaming_fresh_seeds_against_reference(oracle):
+    if not os.path.exists(os.path.join(oracle.REF_DIR, "ref_stream_M5_L20")):
+        pytest.skip("oracle/_ref not built (no /root/reference here): golden fixtures are the pin")
+    rng = np.random.RandomState(11)
+    p = oracle.Params(4, 8, 20, 5, 10)
+    for _ in range(12):
+        seed, eps, W = int(rng.randint(1, 2**30)), float(rng.choice([0.35, 0.44, 0.48, 0.52])), int(rng.randint(2, 8))
+        doped = tuple(sorted(rng.choice(np.arange(3, 12), size=rng.randint(0, 3), replace=False).tolist()))
+        ref = oracle.run_ref_stream(5, 20, 90, seed, eps, W, doped)
+        for dec in (0, 1):
+            s = oracle.Stream(p, seed, eps, W, doped, rng_mode=0, decoder=dec)
+            for k in range(90):
+                o = s.step()
+                assert all(o[f] == ref[k][f] for f in oracle.Stream.FIELDS), (seed, eps, W, doped, dec, k)
