@@ -338,6 +338,102 @@ def bp_traj(argv=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) >= 2 and sys.argv[1] == "sw":
+        sys.exit(streaming(sys.argv[2:]))
     if len(sys.argv) < 2 or sys.argv[1] not in DEFAULTS:
-        raise SystemExit("usage: python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj} ARGS…")
+        raise SystemExit("usage: python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj|sw} ARGS…")
     sys.exit(main(sys.argv[1], sys.argv[2:]))
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming mode: the CIRCULAR build of the reference (`sw INDEX W NUM_DOPED DOPED_POSITIONS…`, BPF:1934-2054)
+# ------------------------------------------------------------------------------------------------
+STREAM_HEADER = ("p BER BLER BER_EXP BLER_EXP bit_err bit_gen block_err block_gen bit_err_exp bit_gen_exp "
+                 "block_err_exp block_gen_exp\n")
+
+
+def stream_filename(p, num_doped, W, index):
+    """results_circular, BPF:535."""
+    return "SC_LDPC_%d_%d_L%d_M%d_DOP%d_BP_Stream_SW%d_Random_BLER_%d.dat" % (p.dv, p.dc, p.L, p.cns_pos, num_doped, W, index)
+
+
+def stream_row(eps, c):
+    """results_circular's row (BPF:547-560) from the eight counters (order of engine.STREAM_COUNTERS)."""
+    ne, be, ee, bee, gb, gbl, gbe, gble = (int(x) for x in c[:8])
+    return "%f %e %e %e %e %d %d %d %d %d %d %d %d\n" % (eps, ne / gb, be / gbl, ee / gbe, bee / gble,
+                                                          ne, gb, be, gbl, ee, gbe, bee, gble)
+
+
+def run_streaming(index, W, doped, opts):
+    """main_streaming: per ε point, decode positions until num_blocks_err_exp >= max_blocks_err or
+    num_blocks_generated_exp >= max_blocks (Def_MaxNumberBlocksError / Def_MaxNumberBlocksSim, BPF:41-42, 2033).
+    The reference runs ONE stream; here `--streams` independent streams (× ranks) advance in lock step, `--chunk`
+    positions per launch, and their counters are summed — the stop rule is applied to the sums after every chunk."""
+    g0 = DEFAULTS["bp_lim_iter"]["grid"]
+    N = opts.N if opts.N else 1000
+    L = opts.L if opts.L else 50
+    p = E.make_params(opts.dv, opts.dc, L, N)
+    grid = GridSpec(opts.eps_ini if opts.eps_ini is not None else g0.eps_ini,
+                    opts.eps_delta if opts.eps_delta is not None else g0.eps_delta,
+                    opts.num_points if opts.num_points else g0.num_points, 0, 0)
+    dist, rank, world = _dist()
+    device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+    os.makedirs(opts.outdir, exist_ok=True)
+    path = os.path.join(opts.outdir, stream_filename(p, len(doped), W, index))
+    for sim in range(grid.num_points):
+        eps = grid.eps(sim)
+        st = E.Streams(p, opts.streams, opts.seed, eps, W, doped,
+                       stream0=(sim * world + rank) * opts.streams, device=device)
+        while True:
+            cnt, _ = st.run(opts.chunk)
+            tot = cnt[:, :8].sum(dim=0)
+            if dist is not None:
+                dist.all_reduce(tot)                    # the only exchange: eight int64 per chunk
+            tot = tot.cpu().numpy()
+            if tot[3] >= opts.max_blocks_err or tot[7] >= opts.max_blocks:
+                break
+        if rank == 0:
+            with open(path, "w" if sim == 0 else "a") as f:
+                if sim == 0:
+                    f.write(STREAM_HEADER)
+                f.write(stream_row(eps, tot))
+            if not opts.quiet:
+                print("%f %e %e %e %e" % (eps, tot[0] / tot[4], tot[1] / tot[5], tot[2] / tot[6], tot[3] / tot[7]), flush=True)
+    return 0
+
+
+def streaming(argv=None):
+    ap = argparse.ArgumentParser(prog="sw", description="doped SC-LDPC streaming window decoder (CIRCULAR build)")
+    ap.add_argument("INDEX", type=int)
+    ap.add_argument("W", type=int)
+    ap.add_argument("NUM_DOPED", type=int)
+    ap.add_argument("DOPED", nargs="*", type=int)
+    ap.add_argument("--dv", type=int, default=4)
+    ap.add_argument("--dc", type=int, default=8)
+    ap.add_argument("--L", type=int, default=0, help="circular buffer length Def_L")
+    ap.add_argument("--N", type=int, default=0)
+    ap.add_argument("--eps-ini", type=float, default=None)
+    ap.add_argument("--eps-delta", type=float, default=None)
+    ap.add_argument("--num-points", type=int, default=0)
+    ap.add_argument("--max-blocks-err", type=int, default=1000, help="Def_MaxNumberBlocksError (BPF:41)")
+    ap.add_argument("--max-blocks", type=int, default=1000000, help="Def_MaxNumberBlocksSim (BPF:42)")
+    ap.add_argument("--streams", type=int, default=512, help="independent streams per rank")
+    ap.add_argument("--chunk", type=int, default=64, help="positions per stream and launch")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--outdir", default=".")
+    ap.add_argument("--quiet", action="store_true")
+    opts = ap.parse_args(argv)
+    if opts.seed is None:
+        opts.seed = int((time.time() % 1) * 1e6)
+    if len(opts.DOPED) < opts.NUM_DOPED:
+        raise SystemExit("NUM_DOPED=%d but only %d positions given" % (opts.NUM_DOPED, len(opts.DOPED)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    rc = run_streaming(opts.INDEX, opts.W, opts.DOPED[:opts.NUM_DOPED], opts)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return rc

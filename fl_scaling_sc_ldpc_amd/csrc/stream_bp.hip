@@ -1,0 +1,436 @@
+// Streaming (circular-buffer) window decoding of a doped SC-LDPC stream — gfx950 kernel.
+//
+// Replaces the body of main_streaming (BPF:1934-2054; BPF = simulators_sc_ldpc/bp_decoding/
+// SC_LDPC_Simulator_BPDecoder_BEC_full_BP_LimIter_OlmosRandomEnsemble.c, a mode the shipped source compiles out
+// with `#undef CIRCULAR`, BPF:33-34): per step
+//     count the generated bits / blocks of the positions being decided (BPF:2017-2028),
+//     decodeBP_SW_circular(pos)      (BPF:1403-1500: classical window, CNs [pos, pos+W), VNs [pos-ms, pos+W),
+//                                     flooding to the window's fixpoint, decision on position pos-ms,
+//                                     size-2 stopping-set expurgation of position pos-2dv+1),
+//     generate_stream_pos(gen_pos++) (BPF:1927-1932: shuffle CN position gen_pos+dv-1, wire VN position gen_pos,
+//                                     draw its channel unless it is doped, reset its messages).
+// One workgroup = one independent stream; the unit of work is one decoded position.  Same node-level machine as
+// sw_bp.hip: S = what the CNs see, one [cnt | Σ id] word per CN slot kept exact, only CNs of the
+// window fire (CNs to the right have never been updated and send erasures; CNs to the left are frozen and, with
+// exact counts, have nothing left to say), every VN a window CN is left with lies inside the VN window.  A window
+// reaches its fixpoint before the next one opens, so the frontier of a new window is just the degree-1 CNs of the
+// position that entered it.  All per-stream state lives in a global-memory blob that persists between launches
+// (ring of L positions: 2-byte adjacency rows, S / VNerased bits, CN words, the last dv socket permutations,
+// counters); LDS holds the frontier queues, the bucket counters of the permutation ranking and per-slot counts.
+// Sampling is keyed like sampler.hip: permutation of CN position c = rank of the Philox words with counter
+// (socket>>2, c, stream id), channel of VN position q = counter (t>>2, 2^31 | q, stream id).
+#include "common.h"
+#include "kernel_util.h"
+
+namespace {
+
+using namespace scldpc_dev;
+
+constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kQCap = 8192, kMaxL = 256;
+enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
+enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_NSCAL = 16 };
+
+struct StateLayout {        // byte offsets inside one stream's blob
+    size_t adj, inter, sbits, ebits, cn, poscnt, tk, gkey, tslot, gidx, counters, total;
+    int wpp;                // 32-bit words of S / VNerased per position
+};
+
+struct Args {
+    int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
+    int ndoped, doped[kMaxDoped];
+    uint32_t seed_lo, seed_hi, thresh;
+    unsigned long long sid0;
+    StateLayout lay;
+    char *state;
+    long long *counters_out;    // [nstreams][10]
+    int32_t *trace;             // optional [nstreams][npos][10]
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ bool position_is_doped(const Args &a, long long pos)     // BPF:1589-1612
+{
+    if (a.ndoped == 0) return false;
+    const int left = a.doped[0], period = a.doped[a.ndoped - 1] + 1, m = (int)(pos % period);
+    if (m < left) return false;
+    for (int i = 0; i < a.ndoped; i++) if (a.doped[i] == m) return true;
+    return false;
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(kThreads) void stream_bp_kernel(const Args a)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds;                                   // nb bucket counters (ranking)
+    uint32_t *q0 = lds + a.nb, *q1 = q0 + kQCap;            // frontier queues
+    uint32_t *wsum = q1 + kQCap, *wpre = wsum + 32;         // scan scratch
+    int *pos_cnt = reinterpret_cast<int *>(wpre + kWaves * kWaves);   // [L] erased VNs per ring slot
+    int *scal = pos_cnt + kMaxL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, ms = a.dv - 1, W = a.W, wpp = a.lay.wpp;
+    char *st = a.state + (size_t)blockIdx.x * a.lay.total;
+    uint16_t *adj = reinterpret_cast<uint16_t *>(st + a.lay.adj);          // [L][V][dv] position-local CN ids
+    uint16_t *inter = reinterpret_cast<uint16_t *>(st + a.lay.inter);      // [dv][S] CN-local id of socket, by CN position % dv
+    uint32_t *Sb = reinterpret_cast<uint32_t *>(st + a.lay.sbits);         // [L][wpp]
+    uint32_t *Eb = reinterpret_cast<uint32_t *>(st + a.lay.ebits);         // [L][wpp] VNerased
+    uint32_t *cn = reinterpret_cast<uint32_t *>(st + a.lay.cn);            // [L*C]
+    int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
+    uint32_t *tk = reinterpret_cast<uint32_t *>(st + a.lay.tk), *gkey = reinterpret_cast<uint32_t *>(st + a.lay.gkey);
+    uint16_t *tslot = reinterpret_cast<uint16_t *>(st + a.lay.tslot), *gidx = reinterpret_cast<uint16_t *>(st + a.lay.gidx);
+    long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
+    const unsigned long long sid = a.sid0 + blockIdx.x;
+    const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
+    auto ldcn = [&](int c) { return __hip_atomic_load(&cn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+    for (int i = tid; i < L; i += kThreads) pos_cnt[i] = pos_cnt_g[i];
+    if (tid < S_NSCAL) scal[tid] = 0;
+    __syncthreads();
+    long long ne = cnt64[C_NE], be = cnt64[C_BE], ee = cnt64[C_EE], bee = cnt64[C_BEE];
+    long long gb = cnt64[C_GB], gbl = cnt64[C_GBL], gbe = cnt64[C_GBE], gble = cnt64[C_GBLE];
+    long long pos = cnt64[C_POS], gen = cnt64[C_GEN];
+
+    // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
+    auto rank_position = [&](long long cpos) {
+        for (int b = tid; b < a.nb; b += kThreads) hist[b] = 0;
+        __syncthreads();
+        for (int q = tid; q < (S + 3) / 4; q += kThreads) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s < S) { tk[s] = r[u]; tslot[s] = (uint16_t)atomicAdd(&hist[r[u] >> a.shift], 1u); }
+            }
+        }
+        __syncthreads();
+        {
+            const int b0 = wave * (ROWS * 64) + lane;
+            uint32_t v[ROWS], inc[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) v[r] = hist[b0 + r * 64];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                hist[b0 + r * 64] = carry + inc[r] - v[r];
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
+            }
+            if (lane == 0) wsum[wave] = carry;
+        }
+        __syncthreads();
+        {
+            const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t inc = wave_inclusive_scan(t);
+            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
+        }
+        auto bucket_base = [&](uint32_t b) -> uint32_t {
+            return b >= (uint32_t)a.nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
+        };
+        for (int s = tid; s < S; s += kThreads) {
+            const uint32_t k = tk[s], g = bucket_base(k >> a.shift) + tslot[s];
+            gkey[g] = k; gidx[g] = (uint16_t)s;
+        }
+        __syncthreads();
+        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+        for (int s = tid; s < S; s += kThreads) {
+            const uint32_t k = tk[s], b = k >> a.shift;
+            const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1), self = g0 + tslot[s];
+            uint32_t rank = g0;
+            for (uint32_t g = g0; g < g1; g++) {
+                if (g == self) continue;
+                const uint32_t k2 = gkey[g];
+                rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+            }
+            dst[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
+        }
+        __syncthreads();
+    };
+
+    // ---- generate_stream_pos(g) + initialize_messages_circular(g) (BPF:1927-1932, 1149-1166) ------------------
+    auto generate = [&](long long g) {
+        rank_position(g + dv - 1);
+        const int slot = (int)(g % L), cslot_new = (int)((g + dv - 1) % L);
+        for (int k = tid; k < C; k += kThreads) cn[cslot_new * C + k] = 0;      // a fresh CN position (BPF:1832-1837)
+        const bool doped = position_is_doped(a, g);
+        int erased_here = 0;
+        for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
+            uint32_t word = 0;
+            if (!doped) {
+#pragma unroll
+                for (int c8 = 0; c8 < 8; c8++) {
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)(w * 8 + c8), 0x80000000u | (uint32_t)g, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) word |= (uint32_t)((r[u] >> 1) < a.thresh) << (c8 * 4 + u);
+                }
+                if (w * 32 + 32 > V) word &= (1u << (V - w * 32)) - 1u;
+            }
+            Sb[slot * wpp + w] = word;
+            erased_here += __popc(word);
+        }
+        {
+            const uint32_t tot = wave_inclusive_scan((uint32_t)erased_here);
+            if (lane == 63 && tot) atomicAdd(&scal[S_ACC], (int)tot);
+        }
+        __syncthreads();
+        if (tid == 0) { pos_cnt[slot] = scal[S_ACC]; scal[S_ACC] = 0; }
+        for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
+            uint16_t loc[8];
+            for (int i = 0; i < dv; i++) {
+                loc[i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
+                adj[((size_t)slot * V + t) * dv + i] = loc[i];
+            }
+            if ((Sb[slot * wpp + (t >> 5)] >> (t & 31)) & 1u)
+                for (int i = 0; i < dv; i++)
+                    atomicAdd(&cn[(int)((g + i) % L) * C + loc[i]], kCntOne + (uint32_t)(slot * V + t));
+        }
+        __syncthreads();
+    };
+
+    if (gen == 0 && pos == 0) {                             // a new stream (BPF:2003-2012)
+        for (int i = tid; i < L * wpp; i += kThreads) { Sb[i] = 0; Eb[i] = 0; }
+        for (int i = tid; i < L * C; i += kThreads) cn[i] = 0;
+        for (int i = tid; i < L; i += kThreads) pos_cnt[i] = 0;
+        __syncthreads();
+        for (int c = 0; c < dv - 1; c++) rank_position(c);  // initialize_arrays_circular (BPF:1808-1813)
+        for (; gen < L / 2; gen++) generate(gen);
+    }
+
+    int genq = 0;                                           // queue generation counter
+    for (int step = 0; step < a.npos; step++, pos++) {
+        const long long pd = pos - ms, pe = pos - 2 * dv + 1;
+        if (pd >= 0 && !position_is_doped(a, pd)) { gb += V; gbl += 1; }        // BPF:2017-2028
+        if (pe >= 0 && !position_is_doped(a, pe)) { gbe += V; gble += 1; }
+
+        // ---- decodeBP_SW_circular(pos) --------------------------------------------------------------------
+        const long long vlo = pd > 0 ? pd : 0;              // VN window [vlo, pos+W)
+        int term = 0;
+        for (long long qq = vlo; qq < pos + W; qq++) term += pos_cnt[(int)(qq % L)];
+        // frontier of a new window: degree-1 CNs of the position(s) that entered it
+        if (tid == 0) { scal[S_PUSH + genq % 3] = 0; scal[S_OVF + genq % 3] = 0; }
+        __syncthreads();
+        {
+            uint32_t *qc = (genq & 1) ? q1 : q0;
+            for (long long qq = (pos == 0 ? 0 : pos + W - 1); qq < pos + W; qq++) {
+                const int cs = (int)(qq % L) * C;
+                for (int k = tid; k < C; k += kThreads)
+                    if ((ldcn(cs + k) >> kCntShift) == 1u) {
+                        const int idx = atomicAdd(&scal[S_PUSH + genq % 3], 1);
+                        if (idx < kQCap) qc[idx] = (uint32_t)(cs + k); else scal[S_OVF + genq % 3] = 1;
+                    }
+            }
+        }
+        __syncthreads();
+        int ncur = min(scal[S_PUSH + genq % 3], kQCap);
+        bool rescan = scal[S_OVF + genq % 3] != 0;
+        const int basemod = (int)(((pos - ms) % L + L) % L);
+        int prec = L * V;
+        for (;;) {
+            uint32_t *qc = (genq & 1) ? q1 : q0, *qn = (genq & 1) ? q0 : q1;
+            int *push_cnt = &scal[S_PUSH + (genq + 1) % 3], *push_ovf = &scal[S_OVF + (genq + 1) % 3];
+            int *rem_cnt = &scal[S_REM + genq % 3];
+            if (tid == 0) { scal[S_PUSH + (genq + 2) % 3] = 0; scal[S_OVF + (genq + 2) % 3] = 0; scal[S_REM + (genq + 1) % 3] = 0; }
+            int removed = 0;
+            auto release = [&](int c) {
+                const uint32_t w = ldcn(c);
+                if ((w >> kCntShift) != 1u) return;
+                const int j = (int)(w & kSumMask), slot_j = j / V, t = j - slot_j * V;
+                const uint32_t bit = 1u << (t & 31);
+                if (!(atomicAnd(&Sb[slot_j * wpp + (t >> 5)], ~bit) & bit)) return;
+                removed++;
+                atomicSub(&pos_cnt[slot_j], 1);
+                const long long qj = pos - ms + ((slot_j - basemod + L) % L);     // absolute position of VN j
+                for (int i = 0; i < dv; i++) {
+                    const long long qc2 = qj + i;
+                    const int c2 = (int)(qc2 % L) * C + adj[(size_t)j * dv + i];
+                    const uint32_t o = atomicSub(&cn[c2], kCntOne + (uint32_t)j) >> kCntShift;
+                    if (o == 2u && qc2 >= pos && qc2 < pos + W) {                  // a window CN is left with one VN
+                        const int idx = atomicAdd(push_cnt, 1);
+                        if (idx < kQCap) qn[idx] = (uint32_t)c2; else *push_ovf = 1;
+                    }
+                }
+            };
+            if (rescan) {
+                // queue overflow: walk every CN of the window (each CN is the lone holder of at most one VN, and a
+                // VN released here may promote further CNs into THIS round — allowed: the window runs to its
+                // fixpoint and only the fixpoint is observable)
+                for (long long qq = pos; qq < pos + W; qq++) {
+                    const int cs = (int)(qq % L) * C;
+                    for (int k = tid; k < C; k += kThreads) release(cs + k);
+                }
+            } else {
+                for (int k = tid; k < ncur; k += kThreads) release((int)qc[k]);
+            }
+            {
+                const uint32_t tot = wave_inclusive_scan((uint32_t)removed);
+                if (lane == 63 && tot) atomicAdd(rem_cnt, (int)tot);
+            }
+            __syncthreads();
+            term -= *rem_cnt;
+            rescan = *push_ovf != 0;
+            ncur = min(*push_cnt, kQCap);
+            genq++;
+            if (term == 0 || term == prec) break;                                 // BPF:1454-1455
+            prec = term;
+        }
+        // decision on position pos-ms (BPF:1445-1449), VNerased := S there
+        int nep = 0;
+        if (pd >= 0) {
+            const int slot = (int)(pd % L);
+            nep = pos_cnt[slot];
+            for (int w = tid; w < wpp; w += kThreads) Eb[slot * wpp + w] = Sb[slot * wpp + w];
+        }
+        ne += nep;
+        if (nep > 0) be += 1;                                                      // BPF:1480-1483
+        __syncthreads();
+        // size-2 stopping-set expurgation of position pos-2dv+1 (get_deg_two_ss, BPF:1227-1283, 1485-1497)
+        if (pe >= 0) {
+            const int slot = (int)(pe % L);
+            int mine = 0;
+            for (int w = tid; w < wpp; w += kThreads) {
+                uint32_t x = Eb[slot * wpp + w];
+                while (x) {
+                    const int b = __ffs((int)x) - 1;
+                    x &= x - 1;
+                    const int t = w * 32 + b, va = slot * V + t;
+                    bool pair = true;
+                    int partner = -1;
+                    for (int i = 0; i < dv; i++) {
+                        const uint32_t s = ldcn((int)((pe + i) % L) * C + adj[(size_t)va * dv + i]);
+                        const int b2 = (int)((s & kSumMask) - (uint32_t)va);
+                        if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
+                        partner = b2;
+                    }
+                    mine += 1 - (pair && partner / V == slot ? 1 : 0);
+                }
+            }
+            const uint32_t tot = wave_inclusive_scan((uint32_t)mine);
+            if (lane == 63 && tot) atomicAdd(&scal[S_ACC], (int)tot);
+            __syncthreads();
+            const int cexp = scal[S_ACC];
+            __syncthreads();
+            if (tid == 0) scal[S_ACC] = 0;
+            if (cexp > 0) { ee += cexp; bee += 1; }
+        }
+        if (a.trace && tid == 0) {
+            int32_t *tr = a.trace + ((size_t)blockIdx.x * a.npos + step) * 10;
+            tr[0] = (int32_t)pos; tr[1] = nep; tr[2] = (int32_t)ne; tr[3] = (int32_t)be; tr[4] = (int32_t)ee; tr[5] = (int32_t)bee;
+            tr[6] = (int32_t)gb; tr[7] = (int32_t)gbl; tr[8] = (int32_t)gbe; tr[9] = (int32_t)gble;
+        }
+        __syncthreads();
+        generate(gen); gen++;                                                      // BPF:2036-2045
+    }
+
+    __syncthreads();
+    for (int i = tid; i < L; i += kThreads) pos_cnt_g[i] = pos_cnt[i];
+    if (tid == 0) {
+        cnt64[C_NE] = ne; cnt64[C_BE] = be; cnt64[C_EE] = ee; cnt64[C_BEE] = bee;
+        cnt64[C_GB] = gb; cnt64[C_GBL] = gbl; cnt64[C_GBE] = gbe; cnt64[C_GBLE] = gble;
+        cnt64[C_POS] = pos; cnt64[C_GEN] = gen;
+        if (a.counters_out) {
+            long long *o = a.counters_out + (size_t)blockIdx.x * 10;
+            o[0] = ne; o[1] = be; o[2] = ee; o[3] = bee; o[4] = gb; o[5] = gbl; o[6] = gbe; o[7] = gble; o[8] = pos; o[9] = gen;
+        }
+    }
+}
+
+int make_state_layout(const scldpc_code_params *p, StateLayout *lay)
+{
+    const size_t L = p->L, V = p->vns_pos, C = p->cns_pos, S = (size_t)p->cns_pos * p->dc, dv = p->dv;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    lay->wpp = (int)((V + 31) / 32);
+    lay->adj = take(L * V * dv * 2);
+    lay->inter = take(dv * S * 2);
+    lay->sbits = take(L * lay->wpp * 4);
+    lay->ebits = take(L * lay->wpp * 4);
+    lay->cn = take(L * C * 4);
+    lay->poscnt = take(L * 4);
+    lay->tk = take(S * 4); lay->gkey = take(S * 4); lay->tslot = take(S * 2); lay->gidx = take(S * 2);
+    lay->counters = take(C_NCOUNT * 8);
+    lay->total = off;
+    return 0;
+}
+
+int check_stream(const scldpc_code_params *p, int W, const char *who)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (p->L > kMaxL || p->L < 2 * p->dv)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: buffer length L=%d outside [%d, %d]", who, p->L, 2 * p->dv, kMaxL);
+    // the stream is generated L/2 positions ahead (BPF:2001): the window and the CNs of its VNs must exist already
+    if (W < 1 || W + p->dv - 1 > p->L / 2)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: need 1 <= W and W + dv - 1 <= L/2 (W=%d, L=%d)", who, W, p->L);
+    if ((int64_t)p->cns_pos * p->dc > 65536 || p->dc > 15 || p->dv > 8 ||
+        (int64_t)p->dc * p->L * p->vns_pos >= (1ll << kDegShift))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: ensemble too large for the streaming kernel", who);
+    return SCLDPC_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_t W)
+{
+    if (int rc = check_stream(p, W, "scldpc_stream_state_bytes")) return rc;
+    StateLayout lay;
+    make_state_layout(p, &lay);
+    return (int64_t)lay.total;
+}
+
+extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
+                                        double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
+                                        int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream)
+{
+    if (int rc = check_stream(p, W, "scldpc_stream_run_device")) return rc;
+    if (nstreams < 0 || npos < 0 || (nstreams > 0 && !d_state))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device: null state or negative count");
+    if (ndoped < 0 || ndoped > kMaxDoped || (ndoped > 0 && !doped_positions))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device: 0 <= ndoped <= %d", kMaxDoped);
+    if (!(eps >= 0.0 && eps <= 1.0))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device: eps=%g outside [0,1]", eps);
+    if (nstreams == 0) return SCLDPC_OK;
+    Args a{};
+    a.dv = p->dv; a.dc = p->dc; a.L = p->L; a.C = p->cns_pos; a.V = p->vns_pos; a.S = p->cns_pos * p->dc; a.W = W;
+    a.npos = npos;
+    int lg = 10;
+    while ((1 << lg) < a.S && lg < 14) lg++;
+    a.nb = 1 << lg; a.shift = 32 - lg; a.lgchunk = lg - 4;
+    a.dc_shift = -1;
+    for (int k = 0; k < 8; k++) if ((1 << k) == p->dc) a.dc_shift = k;
+    a.ndoped = ndoped;
+    for (int d = 0; d < ndoped; d++) {
+        if (doped_positions[d] < 0 || (d > 0 && doped_positions[d] <= doped_positions[d - 1]))
+            return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "doped positions must be non-negative and ascending (BPF:1585-1587)");
+        a.doped[d] = doped_positions[d];
+    }
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.sid0 = stream0;
+    {
+        const double x = eps * 2147483647.0;
+        double c = (double)(uint64_t)x;
+        if (c < x) c += 1.0;
+        a.thresh = (uint32_t)c;
+    }
+    make_state_layout(p, &a.lay);
+    a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
+    const size_t lds_bytes = 4u * ((size_t)a.nb + 2 * kQCap + 32 + kWaves * kWaves + kMaxL + S_NSCAL);
+    const int rows = a.nb / kThreads;
+    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel<1> : rows == 2 ? stream_bp_kernel<2>
+                               : rows == 4 ? stream_bp_kernel<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}

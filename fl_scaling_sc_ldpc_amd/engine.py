@@ -241,3 +241,34 @@ def r1_moments(d_r1, moments=None):
         moments = torch.zeros((3, ncols), dtype=torch.int64, device=d_r1.device)
     check(lib().scldpc_r1_moments_device(T, ncols, d_r1.data_ptr(), moments.data_ptr(), _stream_ptr(d_r1.device)))
     return moments
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming mode (main_streaming, BPF:1934-2054)
+# ------------------------------------------------------------------------------------------------
+STREAM_COUNTERS = ("num_erasures", "num_blocks_err", "num_erasures_exp", "num_blocks_err_exp", "num_bits_generated",
+                   "num_blocks_generated", "num_bits_generated_exp", "num_blocks_generated_exp", "positions", "generated")
+
+
+class Streams:
+    """nstreams independent doped SC-LDPC streams on the device, each a circular buffer of p.L positions."""
+
+    def __init__(self, p, nstreams, seed, eps, W, doped=(), stream0=0, device="cuda:0"):
+        _require_gpu()
+        nbytes = lib().scldpc_stream_state_bytes(C.byref(p), int(W))
+        if nbytes < 0:
+            check(int(nbytes))
+        self.p, self.n, self.seed, self.eps, self.W, self.stream0 = p, nstreams, seed, eps, W, stream0
+        self.doped = tuple(doped)
+        self.state = torch.zeros((nstreams, nbytes), dtype=torch.uint8, device=device)
+        self.counters = torch.zeros((nstreams, 10), dtype=torch.int64, device=device)
+
+    def run(self, npos, trace=False):
+        """Decode npos further positions on every stream; returns (counters int64 [n,10], trace int32 [n,npos,10] | None)."""
+        tr = torch.empty((self.n, npos, 10), dtype=torch.int32, device=self.state.device) if trace else None
+        darr, dptr = _lib.doped_array(self.doped)
+        check(lib().scldpc_stream_run_device(C.byref(self.p), self.n, int(self.seed), int(self.stream0), float(self.eps),
+                                             int(self.W), darr.size, dptr, int(npos), self.state.data_ptr(),
+                                             self.counters.data_ptr(), tr.data_ptr() if tr is not None else None,
+                                             _stream_ptr(self.state.device)))
+        return self.counters, tr

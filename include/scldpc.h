@@ -200,6 +200,24 @@ int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
  * place: [0][s] += #{r1[t][s] != 0}, [1][s] += Σ_t r1[t][s], [2][s] += Σ_t r1[t][s]². */
 int scldpc_r1_moments_device(int32_t ntrials, int32_t ncols, const int32_t *d_r1, int64_t *d_moments, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Streaming mode (main_streaming, BPF:1934-2054 — compiled out in the shipped source by `#undef CIRCULAR`,
+ * BPF:33-34): a circular buffer of p->L positions, periodic doping (is_position_doped_streaming, BPF:1589-1612),
+ * one position decoded by decodeBP_SW_circular (BPF:1403-1500) and one generated (generate_stream_pos,
+ * BPF:1927-1932) per step.  nstreams independent streams run side by side (one workgroup each); the unit of work
+ * is one decoded position.  d_state: nstreams blobs of scldpc_stream_state_bytes(p, W) bytes each, zero-filled by
+ * the caller before a stream's first call and carried from call to call; every call decodes npos further
+ * positions per stream.  Codes and channels are Philox-keyed by (seed, stream0 + stream index, position).
+ * d_counters int64 [nstreams][10]: num_erasures, num_blocks_err, num_erasures_exp, num_blocks_err_exp,
+ * num_bits_generated, num_blocks_generated, num_bits_generated_exp, num_blocks_generated_exp (the arguments of
+ * results_circular, BPF:522-562), positions decoded, positions generated.  d_trace (optional) int32
+ * [nstreams][npos][10]: position, value returned by decodeBP_SW_circular, then the eight counters after it.
+ * Requires W + dv - 1 <= L/2 (the stream is generated L/2 positions ahead of the decoder, BPF:2001). */
+int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_t W);
+int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
+                             double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
+                             int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream);
+
 /* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
  * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),
  * where k is the first trial at which frame_err reaches stop_frame_err (all trials if it never does

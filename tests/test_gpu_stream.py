@@ -1,0 +1,60 @@
+"""Streaming mode on the GPU (-m gpu): stream_bp_kernel through the C-ABI against its CPU twin (the streaming
+oracle with Philox keys and the node-level decoder — itself pinned to the reference's CIRCULAR build), position by
+position, across launches and buffer wrap-arounds."""
+import numpy as np
+import pytest
+
+from conftest import require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    require_gpu()
+    from fl_scaling_sc_ldpc_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("L,N,eps,W,doped,chunks", [
+    (20, 10, 0.45, 6, (), (40, 35, 60)), (20, 10, 0.47, 7, (5, 6), (100, 50)), (20, 10, 0.5, 4, (9,), (90,)),
+    (30, 100, 0.47, 10, (), (70, 30)), (30, 100, 0.49, 12, (10, 11, 12), (100,)),
+    (50, 1000, 0.47, 20, (), (30, 30)), (50, 1000, 0.485, 20, (10, 11, 12), (60,)), (50, 5000, 0.47, 20, (24,), (12,))])
+def test_streams_equal_cpu_twin(E, oracle, L, N, eps, W, doped, chunks):
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    ns = 3
+    st = E.Streams(p, ns, seed=17, eps=eps, W=W, doped=doped, stream0=5)
+    twins = [oracle.Stream(po, 17, eps, W, doped, rng_mode=1, decoder=1, sid=5 + s) for s in range(ns)]
+    for npos in chunks:                                   # the state carries over from launch to launch
+        cnt, tr = st.run(npos, trace=True)
+        tr = tr.cpu().numpy(); cnt = cnt.cpu().numpy()
+        for s in range(ns):
+            for k in range(npos):
+                o = twins[s].step()
+                assert tr[s, k].tolist() == [o[f] for f in oracle.Stream.FIELDS], (L, N, s, k)
+            assert cnt[s, :8].tolist() == [o[f] for f in oracle.Stream.FIELDS[2:]] and cnt[s, 8] == o["pos"] + 1
+
+
+def test_streaming_cli_writes_results_circular_rows(E, tmp_path):
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    B.streaming(["2", "6", "2", "5", "6", "--L", "20", "--N", "10", "--eps-ini", "0.47", "--num-points", "1",
+                 "--max-blocks-err", "50", "--max-blocks", "4000", "--streams", "4", "--chunk", "25", "--seed", "3",
+                 "--outdir", str(tmp_path), "--quiet"])
+    rows = open(tmp_path / "SC_LDPC_4_8_L20_M5_DOP2_BP_Stream_SW6_Random_BLER_2.dat").read().strip().split("\n")
+    assert rows[0] == B.STREAM_HEADER.strip() and len(rows) == 2
+    f = rows[1].split()
+    assert len(f) == 13 and f[0] == "0.470000"
+    ne, gb, be, gbl, ee, gbe, bee, gble = (int(x) for x in f[5:])
+    assert bee >= 50 or gble >= 4000
+    assert float(f[1]) == pytest.approx(ne / gb) and float(f[4]) == pytest.approx(bee / gble)
+    st = E.Streams(E.make_params(4, 8, 20, 10), 4, 3, 0.47, 6, (5, 6), stream0=0)     # same streams, same chunks
+    tot = None
+    while tot is None or (tot[3] < 50 and tot[7] < 4000):
+        tot = st.run(25)[0][:, :8].sum(dim=0).cpu().numpy()
+    assert [ne, be, ee, bee, gb, gbl, gbe, gble] == tot.tolist()
+
+
+def test_streaming_rejects_windows_beyond_the_generated_stream(E):
+    with pytest.raises(E.ScldpcError, match="L/2"):
+        E.Streams(E.make_params(4, 8, 20, 10), 1, 1, 0.4, 9)
