@@ -30,6 +30,7 @@ EXPORTS = (
     "scldpc_peel_sweep_device", "scldpc_peel_sweep_device_adj16",
     "scldpc_peel_pick_device", "scldpc_peel_pick_device_adj16", "scldpc_r1_moments_device",
     "scldpc_stream_state_bytes", "scldpc_stream_run_device",
+    "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16",
 )
 
 
@@ -96,6 +97,8 @@ def lib():
     L.scldpc_peel_pick_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, u64, u64, vp, vp, vp, vp]
     L.scldpc_peel_pick_device_adj16.argtypes = L.scldpc_peel_pick_device.argtypes
     L.scldpc_r1_moments_device.argtypes = [i32, i32, vp, vp, vp]
+    L.scldpc_swc_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.scldpc_swc_bp_device_adj16.argtypes = L.scldpc_swc_bp_device.argtypes
     L.scldpc_stream_state_bytes.argtypes = [pp, i32]
     L.scldpc_stream_state_bytes.restype = i64
     L.scldpc_stream_run_device.argtypes = [pp, i32, u64, u64, dbl, i32, i32, vp, i32, vp, vp, vp, vp]

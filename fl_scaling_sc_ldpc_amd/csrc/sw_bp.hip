@@ -31,6 +31,7 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
 
 struct Args {
     int dv, L, vns_pos, cns_pos, n, nk, W, max_it, init_it;
+    int classical;                  // 0: square window (BPW:628-912); 1: classical window (BPF:627-897)
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     uint32_t *ws;                   // [T][nk] CN words in global memory (G only)
@@ -105,18 +106,22 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
 
     int iters_total = 0;
     int gen = 0;                        // flooding-iteration counter: list gen lives in q[gen&1], its size in scal[S_CNT+gen%3]
-    for (int posW = 0; posW < L; posW++) {
+    // Classical window (BPF:668-684): L+ms windows, the VN window reaches ms positions to the left of the CN window,
+    // position posW-ms is decided when window posW closes, one iteration cap for all windows.
+    const int ms_k = a.dv - 1, last = a.classical ? L + ms_k : L;
+    for (int posW = 0; posW < last; posW++) {
         const int c0 = posW * C, c1 = min(c0 + W * C, nk);                  // BPW:674-676
-        const int jlo = posW * V;                                           // BPW:691 (VNs left of it are frozen)
+        const int qlo = a.classical ? max(posW - ms_k, 0) : posW;           // BPW:691 / BPF:673-684
+        const int jlo = qlo * V;                                            // VNs left of it are frozen
         const int qhi = min(posW + W, L);                                   // BPW:692-693
-        const int cap = (posW == 0) ? a.init_it : a.max_it;                 // BPW:699-702
+        const int cap = a.classical ? a.max_it : ((posW == 0) ? a.init_it : a.max_it);   // BPW:699-702 / BPF:824
         int iter = 0, prec = n, ncur = 0;
         bool scan = true;               // a window opens with a scan of its CNs (the carried list is dropped)
         // erasures inside the window (BPW:791-809).  Read here, where no release is in flight (the scan's
         // snapshot barrier comes first); afterwards kept current from the per-iteration release counter so
         // that every thread takes the same stop decision.
         int term = 0;
-        for (int qq = posW; qq < qhi; qq++) term += pos_cnt[qq];
+        for (int qq = qlo; qq < qhi; qq++) term += pos_cnt[qq];
         for (;;) {
             uint32_t *qc = q[gen & 1], *qn = q[(gen + 1) & 1];
             int *push_cnt = &scal[S_CNT + (gen + 1) % 3], *push_ovf = &scal[S_OVF + (gen + 1) % 3];
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
             const int cnt = pos_cnt[pos];
             ne += cnt;
             if (cnt > 0) be++;
-            if (pos >= ms && pos <= W - 2) p1 += cnt;                       // BPW:846-847
+            // NumErasuresP1: windows ms <= posW <= W-2 (BPW:846-847); the classical window decides position posW-ms
+            if (a.classical ? (pos <= W - 2 - ms) : (pos >= ms && pos <= W - 2)) p1 += cnt;
             const int e = cnt - pos_ss[pos];
             if (e > 0) { ee += e; bee++; }                                  // every position (BPW:903-907)
         }
@@ -254,7 +260,7 @@ int make_layout(const scldpc_code_params *p, int W, bool global_ws, Layout *lay)
 
 }  // namespace
 
-static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16, bool classical,
                         const uint32_t *d_chan_bits, int32_t W, int32_t max_it, int32_t init_it,
                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
@@ -280,6 +286,7 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
     }
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.W = W; a.max_it = max_it; a.init_it = init_it ? init_it : max_it;     // BPW:2101-2102
+    a.classical = classical ? 1 : 0;
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
 
     void (*kern)(const Args);
@@ -300,7 +307,7 @@ extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                                    int32_t W, int32_t max_it, int32_t init_it,
                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj, false, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
 }
 
 extern "C" int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
@@ -308,5 +315,21 @@ extern "C" int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t nt
                                          int32_t W, int32_t max_it, int32_t init_it,
                                          int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj16, true, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj16, true, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+}
+
+extern "C" int scldpc_swc_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                                    const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                                    int32_t W, int32_t max_it,
+                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_sw_bp(p, ntrials, d_vn_adj, false, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits, stream);
+}
+
+extern "C" int scldpc_swc_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                          const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                                          int32_t W, int32_t max_it,
+                                          int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_sw_bp(p, ntrials, d_vn_adj16, true, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits, stream);
 }

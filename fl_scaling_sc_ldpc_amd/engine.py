@@ -151,8 +151,9 @@ def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=Fa
     return {"counters": counters, "rows": rows, "erased": erased}
 
 
-def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None):
-    """decodeBP_SW (square window, BPW:628-912) for a batch resident on the device."""
+def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None, classical=False):
+    """decodeBP_SW for a batch resident on the device: square window (BPW:628-912) or, with classical=True, the
+    classical window kept in BPF:627-897 (init_it unused)."""
     _require_gpu()
     T = d_adj.shape[0]
     assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
@@ -161,6 +162,11 @@ def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=No
     if counters is None:
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    if classical:
+        fn = lib().scldpc_swc_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_swc_bp_device
+        check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it),
+                 counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+        return {"counters": counters, "erased": erased}
     fn = lib().scldpc_sw_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sw_bp_device
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it), int(init_it),
              counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))

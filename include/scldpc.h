@@ -134,6 +134,17 @@ int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                         int32_t W, int32_t max_it, int32_t init_it,
                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
 
+/* decodeBP_SW, classical window — the variant kept in BPF:627-897 (its call is commented out at BPF:2137-2138):
+ * L+dv-1 windows, VNs [posW-ms, posW+W), position posW-ms decided when window posW closes, max_it per window. */
+int scldpc_swc_bp_device(const scldpc_code_params *p, int32_t ntrials,
+                         const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
+                         int32_t W, int32_t max_it,
+                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+int scldpc_swc_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                               const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                               int32_t W, int32_t max_it,
+                               int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+
 /* Compact adjacency variants.  d_vn_adj16 is uint16 [ntrials][n][dv]: the CN index LOCAL to its position
  * (0 .. cns_pos-1).  Edge i of a VN at position pos always lands in CN position pos+i (BPF:1712), so the
  * global id is (pos+i)*cns_pos + local.  Half the HBM bytes of the int32 table (one 8-byte row per VN at

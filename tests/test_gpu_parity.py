@@ -322,3 +322,40 @@ def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, L, N, eps, doped):
         for t in range(T):
             a, c = oracle.sample_philox(po, 2, 40 + t, eps, doped)
             assert (a == A[t]).all() and (c == Cb[t]).all(), (L, N, adj16, t)
+
+
+@pytest.mark.parametrize("name", golden_names(variants=("bpfsw",)))
+def test_classical_window_matches_reference_golden(E, name):
+    """decodeBP_SW of BPF:627-897 (classical window) against the real reference's outputs."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p, T, (d_adj, d_ch) = _golden_inputs(E, g)
+    out = E.sw_bp(p, d_adj, d_ch, m["W"], m["max_it"], want_erased=True, classical=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for col, key in ((0, "ne"), (1, "be"), (2, "ee"), (3, "bee"), (4, "p1"), (7, "nch")):
+        assert (c[:, col] == g[key][:T]).all(), (name, key)
+    if g.has("erased"):
+        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
+
+
+@pytest.mark.parametrize("L,N,W,max_it,eps", [(50, 1000, 20, 6, 0.465), (16, 200, 5, 3, 0.45), (9, 24, 2, 1, 0.5),
+                                              (16, 200, 30, 50, 0.47), (100, 2000, 10, 20, 0.47)])
+def test_classical_window_equals_oracle(E, oracle, L, N, W, max_it, eps):
+    import torch
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    T = 4 if N >= 1000 else 16
+    d_adj, d_ch = E.sample_philox(p, 13, 7, T, eps, adj16=True)
+    out = E.sw_bp(p, d_adj, d_ch, W, max_it, want_erased=True, classical=True)
+    torch.cuda.synchronize()
+    A = E.adj16_to_global(p, d_adj.cpu().numpy())
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n)
+    c = out["counters"].cpu().numpy()
+    er = E.unpack_bits(out["erased"].cpu().numpy(), p.n)
+    for t in range(T):
+        res, erased = oracle.decode_sw(oracle.Graph.from_vn_adj(po, A[t]), bits[t], W, max_it, literal=True, square=False)
+        assert c[t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
+                                     res["num_blocks_err_exp"], res["num_erasures_p1"]], (L, N, W, t)
+        assert c[t, 5] == res["iterations"] and (er[t] == erased).all()

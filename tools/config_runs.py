@@ -54,3 +54,24 @@ mom = torch.zeros((3, steps3 + 1), dtype=torch.int64, device="cuda")
 timed("C3  random-pick peeling N=10000, 290000 steps, in-kernel moments",
       lambda: E.peel_pick(p3, a3, c3, 5000 * 50, steps3, seed=3, want_r1=False, moments=mom), T3)
 timed("C3  full BP N=10000 (workspace)", lambda: E.full_bp(p3, a3, c3), T3)
+
+# C5: doped (4,8) streaming ensemble N=5000, buffer L=50, W=20, doping {10,11,12}
+p5 = E.make_params(4, 8, 50, 5000)
+ns = 512
+st = E.Streams(p5, ns, seed=1, eps=0.485, W=20, doped=(10, 11, 12))
+st.run(4)
+torch.cuda.synchronize(); t0 = time.time()
+cnt, _ = st.run(32)
+torch.cuda.synchronize(); dt = time.time() - t0
+c = cnt[:, :8].sum(0).cpu().numpy()
+print(f"C5  streaming N=5000 L=50 W=20 doped(10,11,12): {ns} streams x 32 positions in {dt * 1e3:.1f} ms = {ns * 32 / dt:.0f} positions/s;"
+      f" BLER {c[1] / max(1, c[5]):.4f}", flush=True)
+p5b = E.make_params(4, 8, 50, 1000)
+st = E.Streams(p5b, 1024, seed=1, eps=0.48, W=20, doped=(10, 11, 12))
+st.run(8)
+torch.cuda.synchronize(); t0 = time.time()
+cnt, _ = st.run(128)
+torch.cuda.synchronize(); dt = time.time() - t0
+c = cnt[:, :8].sum(0).cpu().numpy()
+print(f"C5' streaming N=1000 L=50 W=20 doped(10,11,12): 1024 streams x 128 positions in {dt * 1e3:.1f} ms = {1024 * 128 / dt:.0f} positions/s;"
+      f" BLER {c[1] / max(1, c[5]):.4f}", flush=True)

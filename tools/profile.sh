@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline"
+ARGS="--no-cpu-baseline"   # default steps/warmup: the same kernel work as the plain `python bench.py`
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
