@@ -143,8 +143,9 @@ __global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
                     const uint32_t c2 = (uint32_t)cc[i];
                     const uint32_t o = atomicSub(&cn_state[c2], kCntOne + j);
                     // 2 → 1 inside the window: fires in the next iteration.  CNs right of the window
-                    // are found by the scan of the first window that contains them.
-                    if ((o >> kCntShift) == 2u && (int)c2 < c1) {
+                    // are found by the scan of the first window that contains them; CNs left of it
+                    // (classical window only: VNs of positions posW-ms..posW-1) never send again.
+                    if ((o >> kCntShift) == 2u && (int)c2 < c1 && (int)c2 >= c0) {
                         const int idx = atomicAdd(push_cnt, 1);
                         if (idx < qcap) qn[idx] = c2; else *push_ovf = 1;
                     }
