@@ -30,7 +30,7 @@ EXPORTS = (
     "scldpc_peel_sweep_device", "scldpc_peel_sweep_device_adj16",
     "scldpc_peel_pick_device", "scldpc_peel_pick_device_adj16", "scldpc_r1_moments_device",
     "scldpc_stream_state_bytes", "scldpc_stream_run_device",
-    "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16",
+    "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16", "scldpc_sample_philox_ensemble_device",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
     L.scldpc_glibc_state_reset_perm.argtypes = [pp, vp]
     L.scldpc_sample_glibc_next_host.argtypes = [pp, vp, dbl, i32, vp, i32, vp, vp]
     L.scldpc_sample_philox_device.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
+    L.scldpc_sample_philox_ensemble_device.argtypes = [pp, i32, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes

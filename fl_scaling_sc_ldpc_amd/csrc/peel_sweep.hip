@@ -34,36 +34,48 @@ struct Args {
     const uint32_t *chan;
     int32_t *out;               // [T][8]: lost, lost_exp, blocks_failed_exp, 0, 0, rounds, 0, #erased
     uint32_t *lost_out;         // optional [T][nw]
+    uint32_t *ws;               // [T][ncn] CN words in global memory (ensembles beyond the LDS)
 };
 
 constexpr uint32_t kParentMask = 0x3FFFFFFFu;
 
+// G = true: the words live in a global-memory workspace; plain reads then go past the CU's L1 (agent-scope loads) so
+// that they see what the atomics did in L2.
+template <bool G>
+__device__ __forceinline__ uint32_t ldg(const uint32_t *p, uint32_t x)
+{
+    if constexpr (G) return __hip_atomic_load(&p[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else             return p[x];
+}
+
+template <bool G>
 __device__ __forceinline__ uint32_t uf_find(uint32_t *p, uint32_t x)
 {
     for (;;) {
-        const uint32_t px = p[x] & kParentMask;
+        const uint32_t px = ldg<G>(p, x) & kParentMask;
         if (px == x) return x;
-        const uint32_t gp = p[px] & kParentMask;
+        const uint32_t gp = ldg<G>(p, px) & kParentMask;
         if (gp != px) atomicCAS(&p[x], px, gp);        // path halving; only ever replaces a parent by an ancestor
         x = px;
     }
 }
 
+template <bool G>
 __device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
 {
     for (;;) {
-        a = uf_find(p, a); b = uf_find(p, b);
+        a = uf_find<G>(p, a); b = uf_find<G>(p, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }          // hook the larger root under the smaller
         if (atomicCAS(&p[a], a, b) == a) return;
     }
 }
 
-template <int DV, bool A16>
+template <int DV, bool A16, bool G>
 __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *cn_state = lds + a.lay.cn_state;
+    uint32_t *cn_state = G ? a.ws + (size_t)blockIdx.x * a.ncn : lds + a.lay.cn_state;
     uint32_t *U = lds + a.lay.U;
     uint32_t *fbits = lds + a.lay.fbits;
     uint32_t *frozen = lds + a.lay.frozen;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
         if (tid == 0) { scal[S_PUSH + gn] = 0; scal[S_OVF + gn] = 0; scal[S_REM + gn] = 0; }
         int removed = 0;
         auto release = [&](int c) {
-            const uint32_t w = cn_state[c];
+            const uint32_t w = ldg<G>(cn_state, (uint32_t)c);
             if ((w >> kCntShift) != 1u) return;
             const int j = (int)(w & kSumMask);
             int32_t cc[8];
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             // overflow) takes every other CN < total_size holding one VN: those got there by a transition.
             for (int base = 0; base < cn_lim; base += kBlock) {
                 const int c = base + tid;
-                const bool one = c < cn_lim && (cn_state[c] >> kCntShift) == 1u;
+                const bool one = c < cn_lim && (ldg<G>(cn_state, (uint32_t)c) >> kCntShift) == 1u;
                 bool v, fz;
                 if (iter == 0) { v = one && c >= a.sweep_start; fz = one && c < a.sweep_start; }
                 else           { fz = c < cn_lim && ((frozen[c >> 5] >> (c & 31)) & 1u); v = one && !fz; }
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             int32_t cc[8];
             if (is_lost(w * 32 + b, cc)) {
                 keep |= 1u << b;
-                for (int i = 1; i < dv; i++) uf_unite(cn_state, (uint32_t)cc[0], (uint32_t)cc[i]);
+                for (int i = 1; i < dv; i++) uf_unite<G>(cn_state, (uint32_t)cc[0], (uint32_t)cc[i]);
             }
         }
         U[w] = keep;                                                // U := lost
@@ -212,9 +224,9 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             x &= x - 1;
             int32_t cc[8];
             load_adj<DV, A16>(adj, dv, w * 32 + b, pos_of(w * 32 + b), a.cns_pos, cc);
-            const uint32_t r = uf_find(cn_state, (uint32_t)cc[0]);
+            const uint32_t r = uf_find<G>(cn_state, (uint32_t)cc[0]);
             for (;;) {
-                const uint32_t old = cn_state[r];
+                const uint32_t old = ldg<G>(cn_state, r);
                 if ((old >> 30) == 3u || atomicCAS(&cn_state[r], old, old + (1u << 30)) == old) break;
             }
         }
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             int32_t cc[8];
             load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
             lost++;
-            if ((cn_state[uf_find(cn_state, (uint32_t)cc[0])] >> 30) == 3u) {      // component of > 2 VNs
+            if ((ldg<G>(cn_state, uf_find<G>(cn_state, (uint32_t)cc[0])) >> 30) == 3u) {      // component of > 2 VNs
                 lost_exp++;
                 pos_flag[cc[0] / a.cns_pos] = 1;                    // int(u.birthday / cns_per_pos), PD:160,687
             }
@@ -272,18 +284,30 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
     a.lay.nw = (n + 31) / 32;
-    a.lay.cn_state = take(ncn);
-    a.lay.U = take(a.lay.nw);
-    a.lay.fbits = take(((ncn + 63) / 64) * 2);
-    a.lay.frozen = take(((ncn + 63) / 64) * 2);
-    a.lay.pos_flag = take(p->L + p->dv);
-    a.lay.scal = take(S_NSCAL);
-    int qcap = ((scldpc::kMaxLdsBytes / 4 - off) / 2) & ~3;
-    if (qcap > 8192) qcap = 8192;
-    if (qcap < 256)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                 "scldpc_peel_sweep_device: %d CN words + %d VN bits do not fit 160 KiB of LDS", ncn, n);
+    bool global_ws = false;
+    int qcap = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {                 // CN words in LDS if they fit, else in the workspace
+        off = 0;
+        a.lay.cn_state = take(global_ws ? 0 : ncn);
+        a.lay.U = take(a.lay.nw);
+        a.lay.fbits = take(((ncn + 63) / 64) * 2);
+        a.lay.frozen = take(((ncn + 63) / 64) * 2);
+        a.lay.pos_flag = take(p->L + p->dv);
+        a.lay.scal = take(S_NSCAL);
+        qcap = ((scldpc::kMaxLdsBytes / 4 - off) / 2) & ~3;
+        if (qcap > 8192) qcap = 8192;
+        if (qcap >= 256) break;
+        if (global_ws)
+            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                     "scldpc_peel_sweep_device: %d VN bits + %d scan bits do not fit 160 KiB of LDS", n, ncn);
+        global_ws = true;
+    }
     a.lay.qcap = qcap; a.lay.q0 = take(qcap); a.lay.q1 = take(qcap); a.lay.total = off;
+    if (global_ws) {
+        void *ws = nullptr;
+        if (int rc = scldpc::workspace((size_t)ntrials * ncn * sizeof(uint32_t), &ws)) return rc;
+        a.ws = static_cast<uint32_t *>(ws);
+    }
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.ncn = ncn;
     a.total_size = total_size; a.sweep_start = sweep_start; a.lost_lo = lost_lo; a.lost_hi = lost_hi;
     a.magic_v = (uint32_t)((1ull << 32) / (uint32_t)p->vns_pos) + 1u;
@@ -293,8 +317,11 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: reciprocal division inexact");
     }
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.out = d_out; a.lost_out = d_lost_bits;
-    void (*kern)(const Args) = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true> : peel_sweep_kernel<4, false>)
-                                          : (adj16 ? peel_sweep_kernel<0, true> : peel_sweep_kernel<0, false>);
+    void (*kern)(const Args) = nullptr;
+    if (global_ws) kern = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true, true> : peel_sweep_kernel<4, false, true>)
+                                     : (adj16 ? peel_sweep_kernel<0, true, true> : peel_sweep_kernel<0, false, true>);
+    else           kern = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true, false> : peel_sweep_kernel<4, false, false>)
+                                     : (adj16 ? peel_sweep_kernel<0, true, false> : peel_sweep_kernel<0, false, false>);
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -26,6 +26,7 @@ constexpr int kMaxDoped = 32;
 
 struct SArgs {
     int dv, dc, L, cns_pos, vns_pos, n, S, D, nb, shift, lgchunk, dc_shift, nw;
+    int ens, wrapL, pbits;      // ensemble: 0 Olmos chain, 1 tail-biting (stream and CN position wrap at wrapL = L), 2 protograph
     int ndoped;
     int doped[kMaxDoped];
     uint32_t seed_lo, seed_hi;
@@ -53,7 +54,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 using scldpc_dev::wave_inclusive_scan;
 
 // KMAX = Philox calls per thread per permutation (4 sockets each); ROWS = 64-counter rows each wave scans
-template <int KMAX, int ROWS, bool ADJ16>
+// ENS = 2: protograph chain (sc_ldpc_protograph.py:6-20).  A pass then ranks the S = dv*vns_pos sockets of ONE VN position,
+// socket s = (portion*dv + i)*cns_pos + u; the top pbits bits of its key are its permutation id s / cns_pos, so the one
+// ranking orders all dc permutations of cns_pos elements at once (rank - id*cns_pos = perm value), and the position's
+// rows go out right after its own pass (no ring).  ENS = 0 also serves the tail-biting closure (sc_ldpc.py:41-45): the
+// stream index and the emitted CN position wrap at wrapL.
+template <int KMAX, int ROWS, bool ADJ16, int ENS>
 __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
 {
     extern __shared__ uint32_t lds[];
@@ -83,9 +89,10 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
             const int q = tid + k * kThreads;
             if (q < ncalls) {
                 uint32_t r[4];
-                philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+                philox4x32_10((uint32_t)q, (uint32_t)(p >= a.wrapL ? p - a.wrapL : p), t_lo, t_hi, a.seed_lo, a.seed_hi, r);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
+                    if (ENS == 2) r[u] = ((uint32_t)((q * 4 + u) / a.cns_pos) << (32 - a.pbits)) | (r[u] >> a.pbits);
                     key[k * 4 + u] = r[u];
                     if (q * 4 + u < S) slot[k * 4 + u] = atomicAdd(&hist[r[u] >> a.shift], 1u);
                 }
@@ -172,15 +179,28 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
 #pragma unroll
             for (int e = 0; e < KMAX * 4; e++) {
                 const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
-                if (s < S) wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank[e] >> a.dc_shift : rank[e] / (uint32_t)a.dc);
+                if (ENS == 2) { if (s < S) wp[s] = (uint16_t)(rank[e] - (uint32_t)((s / a.cns_pos) * a.cns_pos)); }
+                else if (s < S) wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank[e] >> a.dc_shift : rank[e] / (uint32_t)a.dc);
             }
         }
         __syncthreads();
         STAMP(4);                                   // rank
 
         // ---- VN position q = p-dv+1 now has all its dv permutations in the ring (BPF:1703-1716)
-        const int qpos = p - (dv - 1);
-        if (qpos >= 0) {
+        const int qpos = ENS == 2 ? p : p - (dv - 1);
+        if (ENS == 2) {
+            for (int t = tid; t < a.vns_pos; t += kThreads) {
+                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
+                const int portion = t / a.cns_pos, u = t - portion * a.cns_pos;
+                for (int i = 0; i < dv; i++) {
+                    const uint32_t l = wp[(size_t)(portion * dv + i) * a.cns_pos + u];
+                    if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l;
+                    else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l;
+                }
+            }
+        } else if (qpos >= 0) {
+            // tail-biting: CN position (qpos+i) mod L (global ids only; the position-local layout has no wrap)
+            auto cpos = [&](int i) { const int c = qpos + i; return c >= a.wrapL ? c - a.wrapL : c; };
             for (int t = tid; t < a.vns_pos; t += kThreads) {
                 const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
                 if (dv == 4) {
@@ -194,15 +214,15 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
                         reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
                     } else {
                         int4 v;
-                        v.x = (qpos + 0) * a.cns_pos + (int)l0; v.y = (qpos + 1) * a.cns_pos + (int)l1;
-                        v.z = (qpos + 2) * a.cns_pos + (int)l2; v.w = (qpos + 3) * a.cns_pos + (int)l3;
+                        v.x = cpos(0) * a.cns_pos + (int)l0; v.y = cpos(1) * a.cns_pos + (int)l1;
+                        v.z = cpos(2) * a.cns_pos + (int)l2; v.w = cpos(3) * a.cns_pos + (int)l3;
                         reinterpret_cast<int4 *>(a.vn_adj)[j] = v;
                     }
                 } else {
                     for (int i = 0; i < dv; i++) {
                         const uint32_t l = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
                         if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l;
-                        else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l;
+                        else       a.vn_adj[j * dv + i] = cpos(i) * a.cns_pos + (int)l;
                     }
                 }
             }
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void sample_philox_big_kernel(const SArgs
 }
 
 template <bool ADJ16>
-int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials, double eps,
+int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t trial0, int32_t ntrials, double eps,
            int32_t ndoped, const int32_t *doped_positions, void *d_adj, uint32_t *d_chan_bits, void *stream,
            const char *who)
 {
@@ -364,6 +384,20 @@ int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t 
     if (a.S > 65536 || p->dv > 8)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %d sockets per position > 65536", who, a.S);
     const bool big = a.S > 8192;
+    if (ensemble < SCLDPC_ENS_OLMOS || ensemble > SCLDPC_ENS_PROTOGRAPH)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: unknown ensemble %d", who, ensemble);
+    a.ens = ensemble; a.wrapL = ensemble == SCLDPC_ENS_TAIL_BITING ? p->L : 0x7FFFFFFF;
+    while ((1 << a.pbits) < p->dc) a.pbits++;
+    if (ensemble != SCLDPC_ENS_OLMOS && big)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the tail-biting / protograph samplers take at most 8192 sockets "
+                                 "per position (got %d)", who, a.S);
+    if (ensemble == SCLDPC_ENS_TAIL_BITING && (ADJ16 || p->L < p->dv))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: tail-biting needs global CN ids (int32 adjacency) and L >= dv", who);
+    if (ensemble == SCLDPC_ENS_PROTOGRAPH) {
+        if (p->dc % p->dv != 0)
+            return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: the protograph ensemble needs dv | dc (vns_pos = (dc/dv) * cns_pos)", who);
+        a.D = p->L;                                     // one pass per VN position
+    }
     if (ADJ16 && p->cns_pos > 65536)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: position-local CN ids need cns_pos <= 65536", who);
     int lg = 10;                                    // nb = power of two >= max(S, kThreads), at most 16384
@@ -416,10 +450,17 @@ int launch(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t 
     const int kmax = ((a.S + 3) / 4 + kThreads - 1) / kThreads;     // 1 or 2
     const int rows = a.nb / kThreads;                               // 1, 2, 4 or 8 rows of 64 per wave
     void (*kern)(const SArgs) = nullptr;
-    if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16>
-                                                                                   : sample_philox_kernel<1, 4, ADJ16>;
-    else           kern = sample_philox_kernel<2, 8, ADJ16>;
-    if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16>;
+    if (ensemble == SCLDPC_ENS_PROTOGRAPH) {
+        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 2> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 2>
+                                                                                          : sample_philox_kernel<1, 4, ADJ16, 2>;
+        else           kern = sample_philox_kernel<2, 8, ADJ16, 2>;
+        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 2>;
+    } else {
+        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 0> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 0>
+                                                                                          : sample_philox_kernel<1, 4, ADJ16, 0>;
+        else           kern = sample_philox_kernel<2, 8, ADJ16, 0>;
+        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 0>;
+    }
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
@@ -433,8 +474,8 @@ extern "C" int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t
                                            int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
                                            int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream)
 {
-    return launch<false>(p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits, stream,
-                         "scldpc_sample_philox_device");
+    return launch<false>(p, SCLDPC_ENS_OLMOS, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits,
+                         stream, "scldpc_sample_philox_device");
 }
 
 extern "C" int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
@@ -442,6 +483,15 @@ extern "C" int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, ui
                                                  const int32_t *doped_positions, uint16_t *d_vn_adj16,
                                                  uint32_t *d_chan_bits, void *stream)
 {
-    return launch<true>(p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_chan_bits, stream,
-                        "scldpc_sample_philox_device_adj16");
+    return launch<true>(p, SCLDPC_ENS_OLMOS, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_chan_bits,
+                        stream, "scldpc_sample_philox_device_adj16");
+}
+
+extern "C" int scldpc_sample_philox_ensemble_device(const scldpc_code_params *p, int32_t ensemble, uint64_t seed,
+                                                    uint64_t trial0, int32_t ntrials, double eps, int32_t ndoped,
+                                                    const int32_t *doped_positions, int32_t *d_vn_adj,
+                                                    uint32_t *d_chan_bits, void *stream)
+{
+    return launch<false>(p, ensemble, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits, stream,
+                         "scldpc_sample_philox_ensemble_device");
 }

@@ -95,9 +95,13 @@ def _is_adj16(d_adj):
     return d_adj.dtype == torch.int16
 
 
-def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None, adj16=False):
+ENSEMBLES = {"olmos": 0, "tail_biting": 1, "protograph": 2}      # SCLDPC_ENS_*
+
+
+def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None, adj16=False, ensemble="olmos"):
     """Throughput-mode sampling on the device (counter-based; see scldpc_sample_philox_device).
-    adj16=True: compact adjacency, int16 tensor [T,n,dv] holding uint16 position-local CN ids."""
+    adj16=True: compact adjacency, int16 tensor [T,n,dv] holding uint16 position-local CN ids (Olmos chain only).
+    ensemble: "olmos" (generate_code / sc_ldpc.gen_slots), "tail_biting" or "protograph" (global CN ids)."""
     _require_gpu()
     if out is None:
         d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int16 if adj16 else torch.int32, device=device)
@@ -105,6 +109,13 @@ def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=
     else:
         d_adj, d_ch = out
     darr, dptr = _lib.doped_array(doped)
+    if ensemble != "olmos":
+        if _is_adj16(d_adj):
+            raise ValueError("the tail-biting / protograph samplers write global CN ids: use adj16=False")
+        check(lib().scldpc_sample_philox_ensemble_device(C.byref(p), ENSEMBLES[ensemble], int(seed), int(trial0),
+                                                         int(ntrials), float(eps), darr.size, dptr, d_adj.data_ptr(),
+                                                         d_ch.data_ptr(), _stream_ptr(d_adj.device)))
+        return d_adj, d_ch
     fn = lib().scldpc_sample_philox_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sample_philox_device
     check(fn(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size, dptr, d_adj.data_ptr(),
              d_ch.data_ptr(), _stream_ptr(d_adj.device)))

@@ -18,7 +18,10 @@ Two sampling modes (keyword `rng`, not in the reference's signatures):
     bit for bit, and both streams are left exactly where the reference leaves them.
   * rng="philox": codes, channels and picks drawn on the device (counter-based, keyed by (seed, trial)); same
     ensemble law, any batch size / GPU count gives the same numbers.
-Protograph and tail-biting ensembles (flags P, TB) are outside this path's scope and raise NotImplementedError.
+Ensembles: the Olmos semi-structured chain (default), its tail-biting closure (flag TB, sc_ldpc.py:41-62), the
+protograph-based chain (flag P, sc_ldpc_protograph.py) and the uncoupled (l,r) ensemble with repeat rejection
+(ldpc.py; simulate_peeling_decoder_ldpc_uncoupled).  P together with TB is refused: the reference reduces the CN
+indices mod L there (PD:204-205), which is not an ensemble.
 """
 import ast
 import pickle
@@ -56,9 +59,56 @@ def gen_erasures(e, L, M, doping_points):
     return mask
 
 
+def gen_slots_tail_biting(l, r, L, M):
+    """sc_ldpc.gen_slots_tail_biting from the global numpy stream: L permutations, edge d of VN position i lands in
+    CN position (i+d) % L (sc_ldpc.py:41-45)."""
+    num_cns = int(l * M / r)
+    cn = np.stack([i * num_cns + np.random.permutation(l * M).reshape(l, M) // r for i in range(L)])
+    tr = np.empty((L, M, l), dtype=np.int32)
+    for d in range(l):
+        tr[:, :, d] = cn[(np.arange(L) + d) % L, d, :]
+    return tr.reshape(L * M, l)
+
+
+def gen_protograph(e, l, r, L, M, doping_points):
+    """gen_users_sc_ldpc_protograph(_doping) (PD:198-241) from the global numpy stream → (transmissions, mask).
+    Position by position: M/num_cns portions × l permutations of num_cns (edge i of VN u of a portion → CN
+    pos*num_cns + i*num_cns + perm_i[u], sc_ldpc_protograph.py:6-20), then rand(M) <= e."""
+    if isinstance(doping_points, dict):
+        raise NameError("name 'position' is not defined")      # the reference's own failure for soft doping (PD:228)
+    num_cns = int(l * M / r)
+    portions = int(M / num_cns)
+    tr = np.empty((L, M, l), dtype=np.int32)
+    mask = np.empty((L, M), dtype=bool)
+    for pos in range(L):
+        rows = [np.stack([i * num_cns + np.random.permutation(num_cns) for i in range(l)]).T for _ in range(portions)]
+        tr[pos] = pos * num_cns + np.vstack(rows)
+        mask[pos] = np.random.rand(M) <= e
+        if pos in doping_points:
+            mask[pos] = False                                   # PD:237
+    return tr.reshape(L * M, l), mask.reshape(L * M)
+
+
+def gen_slots_uncoupled(l, r, N):
+    """ldpc.gen_slots from the global numpy stream: redraw until no VN meets a CN twice (ldpc.py:67-84)."""
+    while True:
+        tr = (np.random.permutation(l * N).reshape(l, N) // r).T
+        if not any(len(np.unique(row)) != l for row in tr):
+            return np.ascontiguousarray(tr, dtype=np.int32)
+
+
+def _sample_numpy(e, l, r, L, M, doping_points, is_protograph, is_tail_biting):
+    """One generate_users() of the reference (PD:618-627, 729-737) → (transmissions int32 [L*M, l], mask)."""
+    if is_protograph:
+        return gen_protograph(e, l, r, L, M, doping_points)
+    tr = gen_slots_tail_biting(l, r, L, M) if is_tail_biting else gen_slots(l, r, L, M)
+    return tr, gen_erasures(e, L, M, doping_points)
+
+
 def _check_flags(is_protograph, is_tail_biting=False):
-    if is_protograph or is_tail_biting:
-        raise NotImplementedError("protograph / tail-biting ensembles are not part of the accelerated path")
+    if is_protograph and is_tail_biting:
+        raise NotImplementedError("protograph + tail-biting: the reference reduces CN indices mod L (PD:204-205), "
+                                  "which merges all CNs of a residue class — not an ensemble this path implements")
 
 
 def _doped_positions(doping_points):
@@ -109,14 +159,16 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
             ch = np.empty((nb, p.nw), dtype=np.uint32)
             states = []
             for t in range(nb):
-                adj[t] = gen_slots(l, r, g.L, M)
-                ch[t] = E.pack_bits(gen_erasures(e, g.L, M, doping_points).astype(np.uint8))
+                adj[t], mask = _sample_numpy(e, l, r, g.L, M, doping_points, is_protograph, is_tail_biting)
+                ch[t] = E.pack_bits(mask.astype(np.uint8))
                 states.append(np.random.get_state())
             d_adj, d_ch = E.to_device(adj, ch, device)
         elif rng == "philox":
             if isinstance(doping_points, dict):
                 raise NotImplementedError("soft doping needs the host sampler (rng='numpy')")
-            d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, _doped_positions(doping_points), device=device, adj16=True)
+            ens = "protograph" if is_protograph else "tail_biting" if is_tail_biting else "olmos"
+            d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, _doped_positions(doping_points), device=device,
+                                          adj16=(ens == "olmos"), ensemble=ens)
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
         out = E.peel_sweep(p, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"].cpu().numpy()
@@ -153,7 +205,6 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
     """Random-pick peeling with the degree-1-CN trajectory (PD:705-789): returns (None, r1, plrs) with
     r1 int64 [num_repeats, num_pd_steps+1] and plrs float64 [num_repeats].  want_moments=True (philox mode) returns
     (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories."""
-    _check_flags(is_protograph)
     if not num_repeats:
         num_repeats = 100
     if isinstance(doping_points, dict):
@@ -169,8 +220,7 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
     if rng == "numpy":
         r1 = np.zeros((num_repeats, num_pd_steps + 1), dtype="int")
         for o in range(num_repeats):                                       # one shared `random` stream: sequential
-            adj = gen_slots(l_deg, r_deg, L, M)
-            mask = gen_erasures(e, L, M, doping_points)
+            adj, mask = _sample_numpy(e, l_deg, r_deg, L, M, doping_points, is_protograph, False)
             d_adj, d_ch = E.to_device(adj[None], E.pack_bits(mask.astype(np.uint8))[None], device)
             st = random.getstate()
             mt = torch.from_numpy(np.array(st[1], dtype=np.uint32).view(np.int32).copy()[None]).to(device)
@@ -189,7 +239,8 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
     moments = None
     for done in range(0, num_repeats, batch):
         nb = min(batch, num_repeats - done)
-        d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device, adj16=True)
+        d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device,
+                                      adj16=not is_protograph, ensemble="protograph" if is_protograph else "olmos")
         if want_moments and moments is None:
             moments = torch.zeros((3, num_pd_steps + 1), dtype=torch.int64, device=device)
         res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done,
@@ -199,6 +250,37 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
         if not want_moments:
             r1_all[done:done + nb] = res["r1"].cpu().numpy()
     return None, (moments.cpu().numpy() if want_moments else r1_all), plrs
+
+
+def simulate_peeling_decoder_ldpc_uncoupled(e, l_deg, r_deg, M, num_repeats=None, device="cuda:0"):
+    """Random-pick peeling on the uncoupled (l,r) ensemble (PD:793-869): returns (None, r1, plrs, num_vns_lst).
+    Graphs and channels come from the global numpy stream (ldpc.gen_slots with its repeat rejection, PD:134-135), the
+    picks from the global `random` stream; both are left where the reference leaves them."""
+    if not num_repeats:
+        num_repeats = 100
+    cpp = int(l_deg / r_deg * M)
+    num_pd_steps = int(M * (e + 0.1))                                      # PD:804
+    # one CN position of cpp CNs; the device kernels only need CN ids < total_size = cpp (global-id adjacency)
+    p = E.CodeParams(l_deg, r_deg, 1, cpp, M)
+    r1 = np.zeros((num_repeats, num_pd_steps + 1), dtype="int")
+    plrs = np.zeros(num_repeats)
+    num_vns_lst = []
+    for o in range(num_repeats):
+        adj = gen_slots_uncoupled(l_deg, r_deg, M)
+        mask = np.random.rand(M) <= e
+        d_adj, d_ch = E.to_device(adj[None], E.pack_bits(mask.astype(np.uint8))[None], device)
+        st = random.getstate()
+        mt = torch.from_numpy(np.array(st[1], dtype=np.uint32).view(np.int32).copy()[None]).to(device)
+        res = E.peel_pick(p, d_adj, d_ch, cpp, num_pd_steps, mt_state=mt)
+        new = mt.cpu().numpy().view(np.uint32)[0]
+        random.setstate((st[0], tuple(int(x) for x in new), st[2]))
+        r1[o] = res["r1"][0].cpu().numpy()
+        n_users, picked = (int(x) for x in res["out"][0, :2].cpu())
+        num_vns_lst.append(n_users)
+        plrs[o] = (n_users - picked) / M                                    # PD:823-826, 866
+        if r1[o, -1] == 1:
+            print("The number of degree-1 CNs at the end of the iterations is 1!!!")
+    return None, r1, plrs, num_vns_lst
 
 
 # ------------------------------------------------------------------------------------------------

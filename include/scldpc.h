@@ -113,6 +113,17 @@ int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint
                                 int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
                                 int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream);
 
+/* The other ensembles of the reference's Python simulators, same keying, global CN ids (int32 rows):
+ *   SCLDPC_ENS_TAIL_BITING  sc_ldpc.gen_slots_tail_biting (sc_ldpc.py:41-62): L permutations, edge i of VN position q
+ *                           lands in CN position (q+i) mod L;
+ *   SCLDPC_ENS_PROTOGRAPH   sc_ldpc_protograph.gen_slots_from_position (:6-20): per VN position dc/dv portions x dv
+ *                           uniform permutations of cns_pos; edge i of VN u of a portion → CN (q+i, perm_i[u]).
+ * SCLDPC_ENS_OLMOS equals scldpc_sample_philox_device.  At most 8192 sockets per position for the two others. */
+enum { SCLDPC_ENS_OLMOS = 0, SCLDPC_ENS_TAIL_BITING = 1, SCLDPC_ENS_PROTOGRAPH = 2 };
+int scldpc_sample_philox_ensemble_device(const scldpc_code_params *p, int32_t ensemble, uint64_t seed, uint64_t trial0,
+                                         int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
+                                         int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Decoders (device)
  * ------------------------------------------------------------------------------------------- */

@@ -79,6 +79,8 @@ def lib():
         L.orc_philox4x32_10.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
         L.orc_sample_philox.argtypes = [P(Params), C.c_uint64, C.c_uint64, C.c_double, C.c_int, P(C.c_int),
                                         i32p, P(C.c_uint32)]
+        L.orc_sample_philox_ens.argtypes = [P(Params), C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_int, P(C.c_int),
+                                            i32p, P(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -139,13 +141,16 @@ def philox4x32_10(ctr, key):
     return [int(x) for x in o]
 
 
-def sample_philox(params, seed, trial, eps, doped=()):
-    """CPU twin of scldpc_sample_philox_device for one trial: (vn_adj int32 [n,dv], chan_bits uint32 [nw])."""
+ENSEMBLES = {"olmos": 0, "tail_biting": 1, "protograph": 2}
+
+
+def sample_philox(params, seed, trial, eps, doped=(), ensemble="olmos"):
+    """CPU twin of scldpc_sample_philox_device(_ensemble) for one trial: (vn_adj int32 [n,dv], chan_bits uint32 [nw])."""
     vn_adj = np.empty((params.n, params.dv), dtype=np.int32)
     chan = np.empty((params.n + 31) // 32, dtype=np.uint32)
     d = (C.c_int * max(1, len(doped)))(*doped)
-    lib().orc_sample_philox(C.byref(params), seed, trial, eps, len(doped), d, _p(vn_adj, C.c_int32),
-                            _p(chan, C.c_uint32))
+    lib().orc_sample_philox_ens(C.byref(params), ENSEMBLES[ensemble], seed, trial, eps, len(doped), d,
+                                _p(vn_adj, C.c_int32), _p(chan, C.c_uint32))
     return vn_adj, chan
 
 

@@ -46,6 +46,55 @@ def gen_erasures(rs, e, l, r, L, M, doping_points=()):
     return mask
 
 
+def gen_slots_tail_biting(rs, l, r, L, M):
+    """sc_ldpc.gen_slots_tail_biting (sc_ldpc.py:41-45, 59-62): only L permutations, VN (i,u) edge d →
+    cn_indices[(i+d) % L][d][u] — the chain closes on itself, CN ids < L*num_cns."""
+    num_cns = int(l * M / r)
+    cn = np.stack([i * num_cns + rs.permutation(l * M).reshape(l, M) // r for i in range(L)])   # [L, l, M]
+    tr = np.empty((L, M, l), dtype=np.int64)
+    for d in range(l):
+        tr[:, :, d] = cn[(np.arange(L) + d) % L, d, :]
+    return tr.reshape(L * M, l)
+
+
+def gen_protograph(rs, e, l, r, L, M, doping_points=()):
+    """gen_users_sc_ldpc_protograph(_doping) (PD:198-241) as (transmissions, mask).  Per VN position, in this order:
+    M/num_cns portions × l draws of rs.permutation(num_cns) (sc_ldpc_protograph.py:6-20: edge i of VN u of a portion
+    → CN seed + i*num_cns + perm_i[u]), then rs.rand(M) <= e.  Hard doping drops the erased VNs of doped positions
+    (PD:237); soft doping hits the reference's undefined name `position` (PD:228) and is not restated."""
+    if isinstance(doping_points, dict):
+        raise NameError("name 'position' is not defined")            # what PD:228 raises
+    num_cns = int(l * M / r)
+    portions = int(M / num_cns)
+    tr = np.empty((L, M, l), dtype=np.int64)
+    mask = np.empty((L, M), dtype=bool)
+    for pos in range(L):
+        rows = [np.stack([i * num_cns + rs.permutation(num_cns) for i in range(l)]).T for _ in range(portions)]
+        tr[pos] = pos * num_cns + np.vstack(rows)
+        mask[pos] = rs.rand(M) <= e
+        if pos in doping_points:
+            mask[pos] = False
+    return tr.reshape(L * M, l), mask.reshape(L * M)
+
+
+def gen_slots_uncoupled(rs, l, r, N):
+    """ldpc.gen_slots (ldpc.py:45-84): rs.permutation(l*N).reshape(l, N) // r, redrawn until no VN meets a CN twice."""
+    while True:
+        tr = (rs.permutation(l * N).reshape(l, N) // r).T.astype(np.int64)
+        if not any(len(np.unique(row)) != l for row in tr):
+            return tr
+
+
+def sample_trial(rs, e, l, r, L, M, doping_points=(), is_protograph=False, is_tail_biting=False):
+    """The draws of one `generate_users()` call (PD:618-627): (transmissions, mask of the VNs that become Users)."""
+    if is_protograph:
+        if is_tail_biting:
+            raise NotImplementedError("protograph + tail-biting: PD:204-205 reduces CN indices mod L, not mod L*num_cns")
+        return gen_protograph(rs, e, l, r, L, M, doping_points)
+    tr = gen_slots_tail_biting(rs, l, r, L, M) if is_tail_biting else gen_slots(rs, l, r, L, M)
+    return tr, gen_erasures(rs, e, l, r, L, M, doping_points)
+
+
 # ------------------------------------------------------------------------------------------------
 # sweep peeling + error statistics (PD:270-313, 591-701, 1077-1095)
 # ------------------------------------------------------------------------------------------------
@@ -134,15 +183,14 @@ def sc_ldpc_trial_stats(tr, mask, l, r, L, M, is_terminated, is_bounded, doping_
 
 
 def simulate_sc_ldpc(seed, e, l, r, L, M, is_terminated, is_bounded, num_repeats=1, max_fuckups=2000,
-                     doping_points=()):
+                     doping_points=(), is_protograph=False, is_tail_biting=False):
     """simulate_sc_ldpc (PD:591-701) after `np.random.seed(seed)`: the informative entries of its 13-tuple, in the
     order (FER, FER_exp, PLR, PLR_exp, #FER_exp, #trials, #lost_exp, #generated, #blocks_failed_exp, #blocks, BLER_exp)."""
     rs = np.random.RandomState(seed)
     Lw = L + (0 if is_bounded else 20) + (0 if is_terminated else 20)
     fu = fu_exp = failed = failed_exp = gen = blk_failed = blk = 0
     for o in range(num_repeats):
-        tr = gen_slots(rs, l, r, Lw, M)
-        mask = gen_erasures(rs, e, l, r, Lw, M, doping_points)
+        tr, mask = sample_trial(rs, e, l, r, Lw, M, doping_points, is_protograph, is_tail_biting)
         s = sc_ldpc_trial_stats(tr, mask, l, r, L, M, is_terminated, is_bounded, doping_points)
         fu += s["frame_err"]; fu_exp += s["frame_err_exp"]; failed += s["num_lost"]; failed_exp += s["num_lost_exp"]
         gen += s["generated"]; blk_failed += s["blocks_failed_exp"]; blk += s["blocks"]
@@ -203,17 +251,32 @@ def random_pick_trial(tr, mask, l, r, L, M, e, is_terminated, rng, num_doping_po
     return r1, (total_generated - total_recovered) / total_generated
 
 
-def simulate_peeling_decoder_ldpc(seed, e, l, r, L, M, is_terminated, num_repeats=1, doping_points=()):
+def simulate_peeling_decoder_ldpc(seed, e, l, r, L, M, is_terminated, num_repeats=1, doping_points=(),
+                                  is_protograph=False):
     """simulate_peeling_decoder_ldpc (PD:705-789) after `np.random.seed(seed); random.seed(seed)`."""
     rs = np.random.RandomState(seed)
     rng = _pyrandom.Random(seed)
     r1s, plrs = [], []
     for _ in range(num_repeats):
-        tr = gen_slots(rs, l, r, L, M)
-        mask = gen_erasures(rs, e, l, r, L, M, doping_points)
+        tr, mask = sample_trial(rs, e, l, r, L, M, doping_points, is_protograph)
         r1, plr = random_pick_trial(tr, mask, l, r, L, M, e, is_terminated, rng, len(doping_points))
         r1s.append(r1); plrs.append(plr)
     return np.stack(r1s), np.array(plrs)
+
+
+def simulate_peeling_decoder_ldpc_uncoupled(seed, e, l, r, M, num_repeats=1):
+    """simulate_peeling_decoder_ldpc_uncoupled (PD:793-869) after `np.random.seed(seed); random.seed(seed)`: one CN
+    position of int(l/r*M) CNs, int(M*(e+0.1)) steps, plr over M.  Returns (r1, plrs, num_vns)."""
+    rs = np.random.RandomState(seed)
+    rng = _pyrandom.Random(seed)
+    r1s, plrs, nv = [], [], []
+    for _ in range(num_repeats):
+        tr = gen_slots_uncoupled(rs, l, r, M)
+        mask = rs.rand(M) <= e                                            # PD:135
+        # L = 1 non-terminated in random_pick_trial's terms: total_size = cpp, steps = int(M*1*(e+0.1)), generated = M
+        r1, plr = random_pick_trial(tr, mask, l, r, 1, M, e, False, rng, 0)
+        r1s.append(r1); plrs.append(plr); nv.append(int(mask.sum()))
+    return np.stack(r1s), np.array(plrs), nv
 
 
 # ------------------------------------------------------------------------------------------------

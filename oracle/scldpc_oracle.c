@@ -488,26 +488,46 @@ static int keyed_cmp(const void *a, const void *b)
     return x->sock < y->sock ? -1 : (x->sock > y->sock);
 }
 
-void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, double eps,
-                       int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits)
+/* ensemble: 0 = Olmos chain (generate_code's law), 1 = its tail-biting closure (sc_ldpc.py:41-45: L permutations,
+ * edge i of VN position q lands in CN position (q+i) mod L), 2 = protograph chain (sc_ldpc_protograph.py:6-20: per VN
+ * position dc/dv portions x dv uniform permutations of cns_pos; edge i of VN u of a portion → CN (q+i, perm_i[u])).
+ * Protograph keys: the top pbits bits of a socket's 32-bit key are its permutation id s / cns_pos, the rest the
+ * Philox word >> pbits, so one ranking of the S sockets ranks every permutation of the position at once. */
+void orc_sample_philox_ens(const orc_params *p, int ensemble, uint64_t seed, uint64_t trial, double eps,
+                           int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits)
 {
-    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, D = p->L + dv - 1, n = orc_n(p);
+    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, n = orc_n(p), L = p->L, C = p->cns_pos;
+    const int D = ensemble == 0 ? L + dv - 1 : L;
     const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     int32_t *cn_local = (int32_t *)malloc(sizeof(int32_t) * (size_t)D * S);
     keyed *ks = (keyed *)malloc(sizeof(keyed) * (size_t)S);
+    int pbits = 0;
+    while ((1 << pbits) < dc) pbits++;
     for (int pos = 0; pos < D; pos++) {
         for (int q = 0; q < (S + 3) / 4; q++) {
             uint32_t ctr[4] = {(uint32_t)q, (uint32_t)pos, (uint32_t)trial, (uint32_t)(trial >> 32)}, r[4];
             orc_philox4x32_10(ctr, key, r);
-            for (int u = 0; u < 4 && q * 4 + u < S; u++) { ks[q * 4 + u].key = r[u]; ks[q * 4 + u].sock = q * 4 + u; }
+            for (int u = 0; u < 4 && q * 4 + u < S; u++) {
+                const int sck = q * 4 + u;
+                ks[sck].key = ensemble == 2 ? ((uint32_t)(sck / C) << (32 - pbits)) | (r[u] >> pbits) : r[u];
+                ks[sck].sock = sck;
+            }
         }
         qsort(ks, (size_t)S, sizeof(keyed), keyed_cmp);
-        for (int rank = 0; rank < S; rank++) cn_local[(size_t)pos * S + ks[rank].sock] = rank / dc;
+        for (int rank = 0; rank < S; rank++)
+            cn_local[(size_t)pos * S + ks[rank].sock] = ensemble == 2 ? rank - (ks[rank].sock / C) * C : rank / dc;
     }
     for (int j = 0; j < n; j++) {
         int pos = j / p->vns_pos, t = j % p->vns_pos;
-        for (int i = 0; i < dv; i++)
-            vn_adj[(size_t)j * dv + i] = (pos + i) * p->cns_pos + cn_local[(size_t)(pos + i) * S + dv * t + i];
+        for (int i = 0; i < dv; i++) {
+            if (ensemble == 2) {
+                const int portion = t / C, u = t % C;
+                vn_adj[(size_t)j * dv + i] = (pos + i) * C + cn_local[(size_t)pos * S + (portion * dv + i) * C + u];
+            } else {
+                const int cp = ensemble == 1 ? (pos + i) % L : pos + i;
+                vn_adj[(size_t)j * dv + i] = cp * C + cn_local[(size_t)cp * S + dv * t + i];
+            }
+        }
     }
     /* erased iff r/RAND_MAX < eps, r = 31-bit draw (BPF:370,1554-1562) ⇔ r < ceil(eps*RAND_MAX) */
     double x = eps * 2147483647.0, c = (double)(uint64_t)x;
@@ -525,4 +545,10 @@ void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, doubl
         for (int j = doped[d] * p->vns_pos; j < (doped[d] + 1) * p->vns_pos; j++)
             chan_bits[j >> 5] &= ~(1u << (j & 31));
     free(cn_local); free(ks);
+}
+
+void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, double eps,
+                       int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits)
+{
+    orc_sample_philox_ens(p, 0, seed, trial, eps, ndoped, doped, vn_adj, chan_bits);
 }

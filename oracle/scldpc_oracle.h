@@ -111,6 +111,8 @@ void orc_trial(const orc_params *p, unsigned seed, double eps, int ndoped, const
 /* CPU twin of the device's Philox-keyed throughput sampler (csrc/sampler.hip); same integers out.
  * chan_bits: bit (j&31) of word j>>5 = 1 iff VN j erased. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_sample_philox_ens(const orc_params *p, int ensemble, uint64_t seed, uint64_t trial, double eps,
+                           int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits);
 void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, double eps,
                        int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits);
 

@@ -15,6 +15,7 @@ from conftest import GOLDEN_DIR, require_gpu
 pytestmark = pytest.mark.gpu
 ER = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_er_*.npz")))
 TR = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_tr_*.npz")))
+UNC = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_unc_*.npz")))
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +41,8 @@ def _tuple11(t):
 @pytest.mark.parametrize("path", ER, ids=[os.path.basename(p)[:-4] for p in ER])
 def test_simulate_sc_ldpc_equals_reference_on_identical_seeds(PD, path):
     z, m, doping = _load(path)
-    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], False, m["is_bounded"], False)
+    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], m.get("is_protograph", False), m["is_bounded"],
+            m.get("is_tail_biting", False))
     for k, s in enumerate(z["seed"]):
         np.random.seed(int(s)); random.seed(int(s))
         t = PD.simulate_sc_ldpc(*args, num_repeats=1, max_fuckups=2000, doping_points=doping)
@@ -71,7 +73,7 @@ def test_simulate_sc_ldpc_stop_rule_leaves_the_stream_where_the_reference_does(P
 @pytest.mark.parametrize("path", TR, ids=[os.path.basename(p)[:-4] for p in TR])
 def test_random_pick_trajectories_equal_reference_on_identical_seeds(PD, path):
     z, m, doping = _load(path)
-    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], False)
+    args = (m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], m.get("is_protograph", False))
     seeds = z["seed"] if m["M"] <= 200 else z["seed"][:2]
     for k, s in enumerate(seeds):
         np.random.seed(int(s)); random.seed(int(s))
@@ -174,8 +176,8 @@ def test_ber_sim_cli_writes_the_reference_rows(PD, tmp_path):
         exp = (e, acc[0] / 6, acc[1] / 6, acc[2] / acc[4], acc[3] / acc[4], int(acc[1]), 6, int(acc[3]), int(acc[4]),
                int(acc[5]), int(acc[6]), acc[5] / acc[6])
         assert row == " ".join(str(x) for x in exp)
-    with pytest.raises(NotImplementedError):
-        PD.simulate_sc_ldpc(0.4, 4, 8, 10, 20, True, True, True, False, 1)
+    with pytest.raises(NotImplementedError):            # protograph + tail-biting (PD:204-205)
+        PD.simulate_sc_ldpc(0.4, 4, 8, 10, 20, True, True, True, True, 1)
 
 
 @pytest.mark.parametrize("L,M,e,term", [(50, 2000, 0.47, False), (20, 2000, 0.46, True), (60, 1000, 0.48, False)])
@@ -210,3 +212,81 @@ def test_peel_pick_notebook_size_exact_stream(PD):
                                                                 P.gen_erasures(rs, 0.47, 4, 8, 6, 10000), 4, 8, 6, 10000,
                                                                 0.47, False, g) for rs in [np.random.RandomState(21)]],
                                           g.random())[1])(random.Random(21))
+
+
+# ---- tail-biting / protograph / uncoupled ensembles --------------------------------------------------
+@pytest.mark.parametrize("path", UNC, ids=[os.path.basename(p)[:-4] for p in UNC])
+def test_uncoupled_ensemble_equals_reference_on_identical_seeds(PD, path):
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    for k, s in enumerate(z["seed"]):
+        np.random.seed(int(s)); random.seed(int(s))
+        none, r1, plrs, nv = PD.simulate_peeling_decoder_ldpc_uncoupled(m["e"], m["l"], m["r"], m["M"], 1)
+        assert none is None and (r1[0] == z["r1"][k]).all() and plrs[0] == z["plr"][k] and nv == [int(z["num_vns"][k])]
+    s0 = int(z["seed"][0])
+    np.random.seed(s0); random.seed(s0)
+    _, r1, plrs, nv = PD.simulate_peeling_decoder_ldpc_uncoupled(m["e"], m["l"], m["r"], m["M"], 2)
+    assert (r1 == z["multi2_r1"]).all() and (plrs == z["multi2_plr"]).all() and nv == z["multi2_num_vns"].tolist()
+
+
+@pytest.mark.parametrize("ens", ["tail_biting", "protograph"])
+@pytest.mark.parametrize("L,M,e,doped", [(10, 20, 0.45, ()), (12, 40, 0.5, (3, 4)), (50, 1000, 0.48, ()), (7, 1024, 0.3, (0,))])
+def test_ensemble_sampler_equals_cpu_twin(PD, oracle, ens, L, M, e, doped):
+    """scldpc_sample_philox_ensemble_device against orc_sample_philox_ens, plus the structure the reference's samplers
+    guarantee: every CN of a populated position has exactly dc sockets, edge i of position q lands in position
+    (q+i) [mod L when tail-biting]; protograph: each (portion, edge) block is a permutation of the position's CNs."""
+    E = PD.E
+    p = E.CodeParams(4, 8, L, M // 2, M)
+    po = oracle.Params(4, 8, L, M // 2, M)
+    T = 3
+    d_adj, d_ch = E.sample_philox(p, 91, 5, T, e, doped, ensemble=ens)
+    A, Cb = d_adj.cpu().numpy(), d_ch.cpu().numpy().view(np.uint32)
+    C = M // 2
+    for t in range(T):
+        ra, rc = oracle.sample_philox(po, 91, 5 + t, e, doped, ensemble=ens)
+        assert (A[t] == ra).all() and (Cb[t] == rc).all(), (ens, L, M, t)
+        a = A[t].reshape(L, M, 4)
+        for i in range(4):
+            want = (np.arange(L) + i) % L if ens == "tail_biting" else np.arange(L) + i
+            assert ((a[:, :, i] // C) == want[:, None]).all()
+        if ens == "tail_biting":
+            assert (np.bincount(A[t].ravel(), minlength=L * C) == 8).all()
+        else:
+            loc = (a % C).reshape(L, 2, C, 4)
+            assert (np.sort(loc, axis=2) == np.arange(C)[None, None, :, None]).all()
+
+
+@pytest.mark.parametrize("ens,term,bounded", [("tail_biting", False, True), ("tail_biting", True, False),
+                                              ("protograph", True, True), ("protograph", False, False)])
+@pytest.mark.parametrize("L,M,e", [(12, 40, 0.47), (20, 200, 0.5)])
+def test_sweep_and_pick_on_the_other_ensembles_equal_oracle(PD, oracle, ens, term, bounded, L, M, e):
+    from oracle import pd_oracle as P
+    E = PD.E
+    g = PD._Geometry(4, 8, L, M, term, bounded, [])
+    T = 12
+    d_adj, d_ch = E.sample_philox(g.params, 17, 40, T, e, ensemble=ens)
+    out = E.peel_sweep(g.params, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"].cpu().numpy()
+    A = d_adj.cpu().numpy().astype(np.int64)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), g.params.n).astype(bool)
+    for t in range(T):
+        s = P.sc_ldpc_trial_stats(A[t], bits[t], 4, 8, L, M, term, bounded)
+        assert (out[t, 0], out[t, 1], out[t, 2]) == (s["num_lost"], s["num_lost_exp"], s["blocks_failed_exp"]), (ens, t)
+    t13 = PD.simulate_sc_ldpc(e, 4, 8, L, M, term, ens == "protograph", bounded, ens == "tail_biting", num_repeats=T,
+                              rng="philox", seed=17, batch=5)
+    assert t13[5] == T
+    if ens == "protograph":
+        none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, True, 4, [], rng="philox", seed=23, batch=3)
+        p = E.CodeParams(4, 8, L, M // 2, M)
+        da, dc = E.sample_philox(p, 23, 0, 4, e, ensemble="protograph")
+        A2 = da.cpu().numpy().astype(np.int64)
+        b2 = E.unpack_bits(dc.cpu().numpy(), p.n).astype(bool)
+        for t in range(4):
+            ref_r1, ref_plr = P.random_pick_trial(A2[t], b2[t], 4, 8, L, M, e, term, P.PhiloxPickStream(23, t))
+            assert (r1[t] == ref_r1).all() and plrs[t] == ref_plr
+
+
+def test_protograph_with_tail_biting_is_refused(PD):
+    with pytest.raises(NotImplementedError):
+        PD.simulate_sc_ldpc(0.45, 4, 8, 10, 20, True, True, True, True, num_repeats=1)
+    with pytest.raises(NameError):                      # the reference's own failure for soft doping there (PD:228)
+        PD.simulate_sc_ldpc(0.45, 4, 8, 10, 20, True, True, True, False, num_repeats=1, doping_points={3: 0.5})

@@ -139,3 +139,31 @@ def test_literal_and_peel_models_agree_on_random_small_graphs(oracle):
             for k in ("num_erasures", "num_blocks_err", "num_erasures_exp", "num_blocks_err_exp",
                       "num_erasures_p1", "iterations", "he"):
                 assert a[k] == b[k], (M, L, seed, eps, W, cap, init, k)
+
+
+@pytest.mark.parametrize("ens", ["olmos", "tail_biting", "protograph"])
+def test_philox_ensemble_twins_have_the_reference_samplers_structure(oracle, ens):
+    """orc_sample_philox_ens (the CPU twin of the device samplers): socket counts, position structure and — for the
+    protograph chain — one permutation of the position's CNs per (portion, edge), as sc_ldpc.py / sc_ldpc_protograph.py
+    construct them; plus a first-moment check of the permutation law (uniform position of a fixed socket)."""
+    L, M, C = 9, 24, 12
+    po = oracle.Params(4, 8, L, C, M)
+    seen = np.zeros(C, dtype=np.int64)
+    for t in range(600):
+        adj, ch = oracle.sample_philox(po, 3, t, 0.4, ensemble=ens)
+        a = adj.reshape(L, M, 4)
+        for i in range(4):
+            want = (np.arange(L) + i) % L if ens == "tail_biting" else np.arange(L) + i
+            assert ((a[:, :, i] // C) == want[:, None]).all()
+        if ens == "tail_biting":
+            assert (np.bincount(adj.ravel(), minlength=L * C) == 8).all()
+        elif ens == "protograph":
+            loc = (a % C).reshape(L, 2, C, 4)
+            assert (np.sort(loc, axis=2) == np.arange(C)[None, None, :, None]).all()
+        else:
+            cnt = np.bincount(adj.ravel(), minlength=(L + 3) * C).reshape(L + 3, C)
+            assert (cnt[3:L] == 8).all() and cnt[0].sum() == M and cnt[L + 2].sum() == M
+        seen[a[4, 5, 2] % C] += 1
+    # uniform over the C CNs of the position: chi-square with C-1 = 11 dof, 99.9 % quantile 31.3
+    chi2 = ((seen - 600 / C) ** 2 / (600 / C)).sum()
+    assert chi2 < 31.3, (ens, seen)

@@ -12,6 +12,7 @@ from conftest import GOLDEN_DIR
 
 ER = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_er_*.npz")))
 TR = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_tr_*.npz")))
+UNC = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_unc_*.npz")))
 
 
 def _load(path):
@@ -30,18 +31,23 @@ def test_simulate_sc_ldpc_tuple(path):
     seeds = z["seed"] if m["M"] <= 200 else z["seed"][:3]
     for k, s in enumerate(seeds):
         got = P.simulate_sc_ldpc(int(s), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], m["is_bounded"],
-                                 1, 2000, doping)
+                                 1, 2000, doping, m.get("is_protograph", False), m.get("is_tail_biting", False))
         assert np.allclose(got, z["tuple11"][k], rtol=0, atol=1e-15), (path, s, got, z["tuple11"][k])
     if m["M"] <= 200:
         got = P.simulate_sc_ldpc(int(z["seed"][0]), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"],
-                                 m["is_bounded"], 3, 2000, doping)
+                                 m["is_bounded"], 3, 2000, doping, m.get("is_protograph", False),
+                                 m.get("is_tail_biting", False))
         assert np.allclose(got, z["multi3"], rtol=0, atol=1e-15)
     if "transmissions" in z.files:                      # the sampled inputs themselves
         Lw = m["L"] + (0 if m["is_bounded"] else 20) + (0 if m["is_terminated"] else 20)
         for k in range(min(5, len(seeds))):
             rs = np.random.RandomState(int(seeds[k]))
-            tr = P.gen_slots(rs, m["l"], m["r"], Lw, m["M"])
-            mask = rs.rand(Lw * m["M"]) <= m["e"]
+            if m.get("is_protograph") or m.get("is_tail_biting"):
+                tr, mask = P.sample_trial(rs, m["e"], m["l"], m["r"], Lw, m["M"], doping if m.get("is_protograph") else (),
+                                          m.get("is_protograph", False), m.get("is_tail_biting", False))
+            else:
+                tr = P.gen_slots(rs, m["l"], m["r"], Lw, m["M"])
+                mask = rs.rand(Lw * m["M"]) <= m["e"]
             assert (tr == z["transmissions"][k]).all() and (mask == z["mask"][k].astype(bool)).all()
 
 
@@ -52,12 +58,28 @@ def test_random_pick_trajectories(path):
     seeds = z["seed"] if m["M"] <= 200 else z["seed"][:1]
     for k, s in enumerate(seeds):
         r1, plr = P.simulate_peeling_decoder_ldpc(int(s), m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"],
-                                                  1, doping)
+                                                  1, doping, m.get("is_protograph", False))
         assert (r1[0] == z["r1"][k]).all() and plr[0] == z["plr"][k], (path, s)
     if m["M"] <= 200:
         r1, plr = P.simulate_peeling_decoder_ldpc(int(z["seed"][0]), m["e"], m["l"], m["r"], m["L"], m["M"],
-                                                  m["is_terminated"], 2, doping)
+                                                  m["is_terminated"], 2, doping, m.get("is_protograph", False))
         assert (r1 == z["multi2_r1"]).all() and (plr == z["multi2_plr"]).all()
+
+
+@pytest.mark.parametrize("path", UNC, ids=[os.path.basename(p)[:-4] for p in UNC])
+def test_uncoupled_ensemble(path):
+    """ldpc.gen_slots (repeat rejection) + simulate_peeling_decoder_ldpc_uncoupled (PD:793-869)."""
+    from oracle import pd_oracle as P
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    for k, s in enumerate(z["seed"]):
+        rs = np.random.RandomState(int(s))
+        tr = P.gen_slots_uncoupled(rs, m["l"], m["r"], m["M"])
+        assert (tr == z["transmissions"][k]).all() and ((rs.rand(m["M"]) <= m["e"]) == z["mask"][k].astype(bool)).all()
+        r1, plr, nv = P.simulate_peeling_decoder_ldpc_uncoupled(int(s), m["e"], m["l"], m["r"], m["M"], 1)
+        assert (r1[0] == z["r1"][k]).all() and plr[0] == z["plr"][k] and nv[0] == z["num_vns"][k]
+    r1, plr, nv = P.simulate_peeling_decoder_ldpc_uncoupled(int(z["seed"][0]), m["e"], m["l"], m["r"], m["M"], 2)
+    assert (r1 == z["multi2_r1"]).all() and (plr == z["multi2_plr"]).all() and nv == z["multi2_num_vns"].tolist()
 
 
 def test_randbelow_is_random_choice():
