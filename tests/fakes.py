@@ -59,3 +59,26 @@ class FakeSimulator(B.Simulator):
     def _accumulate(self, allcnt, run, stop):
         run.copy_(torch.from_numpy(numpy_accumulate(allcnt.numpy(), run.numpy(), stop)))
         return run
+
+
+class FakeStreams:
+    """Stand-in for engine.Streams (streaming mode): cumulative per-stream counters as a pure function of the global
+    stream id and the number of positions decoded so far."""
+
+    def __init__(self, p, nstreams, seed, eps, W, doped, stream0=0, device=None):
+        self.ids = np.arange(stream0, stream0 + nstreams, dtype=np.int64)
+        self.done = 0
+        self.vns = p.vns_pos
+        self.cnt = np.zeros((nstreams, 8), dtype=np.int64)
+
+    def run(self, npos):
+        for k in range(self.done, self.done + npos):
+            h = (self.ids * 2654435761 + k * 40503 + 977) & 0xFFFFFFFF
+            bad = (h >> 5) % 11 == 0
+            ne = np.where(bad, 1 + h % 37, 0)
+            ee = np.where(bad & (ne > 2), ne, 0)
+            self.cnt += np.stack([ne, bad.astype(np.int64), ee, (ee > 0).astype(np.int64),
+                                  np.full_like(ne, self.vns), np.ones_like(ne), np.full_like(ne, self.vns),
+                                  np.ones_like(ne)], axis=1)
+        self.done += npos
+        return torch.from_numpy(self.cnt.copy()), None

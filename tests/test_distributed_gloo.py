@@ -49,3 +49,43 @@ def test_two_ranks_equal_one_rank():
     for i, (batch, stop, max_frames) in enumerate(cases):
         ref = numpy_accumulate(fake_counters(1, np.arange(max_frames), p.n, p.L), np.zeros(E.NRUN), stop).tolist()
         assert got[0][i] == ref and got[1][i] == ref, (cases[i], got[0][i], ref)
+
+
+def _stream_worker(rank, world, port, outdir, streams):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from fakes import FakeStreams
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    B.E.Streams = FakeStreams                      # the device work; everything else is the product's driver
+    opts = argparse.Namespace(N=20, L=12, dv=4, dc=8, eps_ini=0.49, eps_delta=0.01, num_points=3, streams=streams, chunk=5,
+                              seed=1, outdir=outdir, quiet=True, max_blocks_err=40, max_blocks=100000)
+    B.run_streaming(0, 4, [3], opts)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_streaming_driver_two_ranks_equal_one_rank(tmp_path):
+    """main_streaming's driver: 2 ranks x S streams stop at the same chunk and write the same results_circular rows as
+    1 rank x 2S streams (the only exchange is the all-reduce of eight int64 per chunk)."""
+    ctx = mp.get_context("spawn")
+    port = 31500 + os.getpid() % 2000
+    d2, d1 = str(tmp_path / "two"), str(tmp_path / "one")
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, d2, 6)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    one = ctx.Process(target=_stream_worker, args=(0, 1, port + 1, d1, 12))
+    one.start(); one.join(timeout=120)
+    assert one.exitcode == 0
+    f2, f1 = sorted(os.listdir(d2)), sorted(os.listdir(d1))
+    assert f1 == f2 and len(f1) == 1
+    a, b = open(os.path.join(d2, f2[0])).read(), open(os.path.join(d1, f1[0])).read()
+    assert a == b and len(a.splitlines()) == 4          # header + one row per eps point
