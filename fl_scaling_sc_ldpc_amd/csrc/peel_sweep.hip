@@ -86,7 +86,6 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int trial = blockIdx.x;
     const int n = a.n, ncn = a.ncn, dv = (DV ? DV : a.dv), cn_lim = a.total_size, nw = a.lay.nw, qcap = a.lay.qcap;
-    const int V = a.vns_pos;
     const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
     const uint32_t *ch = a.chan + (size_t)trial * nw;
     auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };

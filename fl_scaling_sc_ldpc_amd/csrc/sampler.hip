@@ -59,7 +59,11 @@ using scldpc_dev::wave_inclusive_scan;
 // ranking orders all dc permutations of cns_pos elements at once (rank - id*cns_pos = perm value), and the position's
 // rows go out right after its own pass (no ring).  ENS = 0 also serves the tail-biting closure (sc_ldpc.py:41-45): the
 // stream index and the emitted CN position wrap at wrapL.
-template <int KMAX, int ROWS, bool ADJ16, int ENS>
+// FINE: four byte-wide bucket counters per 32-bit word of `hist` — four times as many buckets in the same LDS, so that a
+// bucket holds 0.24 keys on average instead of 1 and the ranking loop below runs ~3 steps per wave instead of ~7.  After the
+// scan a word holds [exclusive prefix:14 | c0:4 | c1:4 | c2:4 | c3:4].  A bucket with 16 keys (never, for Philox keys: the
+// mean is 0.24) traps instead of corrupting its neighbour.
+template <int KMAX, int ROWS, bool ADJ16, int ENS, bool FINE>
 __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
 {
     extern __shared__ uint32_t lds[];
@@ -68,13 +72,13 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
     uint16_t *gidx = reinterpret_cast<uint16_t *>(lds + a.off_gidx);   // S socket ids, same order
     uint16_t *win = reinterpret_cast<uint16_t *>(lds + a.off_win);     // ring of dv × S CN-local ids
     uint32_t *wsum = lds + a.off_wsum;                              // per-wave totals for the scan
-    uint32_t *wpre = wsum + 32;                                     // [wave][16] exclusive prefix of wsum, one copy per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long trial = a.trial0 + blockIdx.x;
     const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     const int S = a.S, nb = a.nb, dv = a.dv;
     const int ncalls = (S + 3) >> 2;
+    const int kshift = FINE ? a.shift - 2 : a.shift;                // key >> kshift = bucket
 
     STAMP_DECL
     for (int p = 0; p < a.D; p++) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
         STAMP(0);                                   // clear
 
         // ---- keys + bucket histogram; the atomic's return value is the arrival slot in the bucket
-        uint32_t key[KMAX * 4], slot[KMAX * 4];
+        uint32_t key[KMAX * 4], slot[KMAX * 4], crowded = 0;
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
             const int q = tid + k * kThreads;
@@ -94,59 +98,98 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
                 for (int u = 0; u < 4; u++) {
                     if (ENS == 2) r[u] = ((uint32_t)((q * 4 + u) / a.cns_pos) << (32 - a.pbits)) | (r[u] >> a.pbits);
                     key[k * 4 + u] = r[u];
-                    if (q * 4 + u < S) slot[k * 4 + u] = atomicAdd(&hist[r[u] >> a.shift], 1u);
+                    if (q * 4 + u < S) {
+                        if (FINE) {
+                            const uint32_t b = r[u] >> kshift, sh = (b & 3u) * 8u;
+                            slot[k * 4 + u] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFFu;
+                            crowded = max(crowded, slot[k * 4 + u]);
+                        } else {
+                            slot[k * 4 + u] = atomicAdd(&hist[r[u] >> kshift], 1u);
+                        }
+                    }
                 }
             }
         }
+        if (FINE && crowded >= 15u) __builtin_trap();                // a bucket count must fit its nibble (never happens)
         __syncthreads();
         STAMP(1);                                   // keys + histogram
 
-        // ---- exclusive scan of the bucket counts.  Each wave owns nb/16 contiguous counters = ROWS rows of
-        //      64; the rows are scanned independently (DPP) and chained by their totals; the slice bases go to
-        //      wsum[] and are added by the readers:  base(b) = hist[b] + Σ_{w < b>>lgchunk} wsum[w].
+        // ---- exclusive scan of the bucket counts.  Each wave owns nb/16 contiguous words = ROWS rows of 64; the rows are
+        //      scanned independently (DPP) and chained by their totals; after the barrier every wave scans the 16 slice
+        //      totals itself and folds its own slice base into its words, so a reader needs ONE word per key:
+        //      FINE word = [global exclusive prefix:14 | c0:4 | c1:4 | c2:4 | c3:4]  (base of bucket k = prefix + c0..c(k-1)).
+        uint32_t mine[ROWS];
         {
             const int base = wave * (ROWS * 64) + lane;
-            uint32_t v[ROWS], inc[ROWS];
+            uint32_t v[ROWS], inc[ROWS], raw[ROWS];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) v[r] = hist[base + r * 64];
+            for (int r = 0; r < ROWS; r++) {
+                raw[r] = hist[base + r * 64];
+                v[r] = FINE ? (raw[r] * 0x01010101u) >> 24 : raw[r];        // FINE: keys in the word's four buckets
+            }
 #pragma unroll
             for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
             uint32_t carry = 0;
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                hist[base + r * 64] = carry + inc[r] - v[r];
+                const uint32_t excl = carry + inc[r] - v[r];
+                if (FINE) {     // byte counts (each < 16, checked above) → nibbles
+                    const uint32_t x = raw[r];
+                    mine[r] = excl | ((x & 0xFu) << 14) | (((x >> 8) & 0xFu) << 18) | (((x >> 16) & 0xFu) << 22) | ((x >> 24) << 26);
+                } else {
+                    mine[r] = excl;
+                }
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
             }
             if (lane == 0) wsum[wave] = carry;
         }
         __syncthreads();
         STAMP(2);                                   // scan
-        // exclusive prefix of the 16 slice totals: every wave scans them itself (lanes 0-15, one DPP row) into
-        // its own 16 words of LDS — no further barrier, and a 2-read bucket base instead of a select chain
         {
             const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
             const uint32_t inc = wave_inclusive_scan(t);
-            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
+            const uint32_t slice = (uint32_t)__builtin_amdgcn_readlane((int)(inc - t), wave);
+            const int base = wave * (ROWS * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) hist[base + r * 64] = mine[r] + slice;
         }
-        auto bucket_base = [&](uint32_t b) -> uint32_t {
-            return b >= (uint32_t)nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
-        };
+        __syncthreads();
 
-        // ---- group (key, socket) by bucket
+        // ---- group (key, socket) by bucket.  The bucket words of the thread's keys are read together (indices clamped
+        //      instead of branched on), one wait, then the stores.
         uint32_t g0s[KMAX * 4], g1s[KMAX * 4];
+        {
+            constexpr int E = KMAX * 4;
+            const uint32_t nbk = FINE ? 4u * (uint32_t)nb : (uint32_t)nb;
+            uint32_t b0[E], h0[E], h1[E];
+            bool ok[E];
 #pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-            const int q = tid + k * kThreads;
+            for (int e = 0; e < E; e++) {
+                const int q = tid + (e >> 2) * kThreads, sck = q * 4 + (e & 3);
+                ok[e] = q < ncalls && sck < S;
+                b0[e] = ok[e] ? key[e] >> kshift : 0u;
+                h0[e] = hist[FINE ? b0[e] >> 2 : b0[e]];
+                if (!FINE) h1[e] = hist[min(b0[e] + 1u, nbk - 1u)];
+            }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int s = q * 4 + u;
-                if (q < ncalls && s < S) {
-                    const uint32_t b = key[k * 4 + u] >> a.shift;
-                    g0s[k * 4 + u] = bucket_base(b);
-                    g1s[k * 4 + u] = bucket_base(b + 1);
-                    const uint32_t g = g0s[k * 4 + u] + slot[k * 4 + u];
-                    gkey[g] = key[k * 4 + u];
-                    gidx[g] = (uint16_t)s;
+            for (int e = 0; e < E; e++) {
+                if (FINE) {
+                    const uint32_t k = b0[e] & 3u, h = h0[e];
+                    const uint32_t c0 = (h >> 14) & 15u, c1 = (h >> 18) & 15u, c2 = (h >> 22) & 15u;
+                    g0s[e] = (h & 0x3FFFu) + (k > 0 ? c0 : 0u) + (k > 1 ? c1 : 0u) + (k > 2 ? c2 : 0u);
+                    g1s[e] = g0s[e] + ((h >> (14u + 4u * k)) & 15u);
+                } else {
+                    g0s[e] = h0[e];
+                    g1s[e] = b0[e] + 1u >= nbk ? (uint32_t)S : h1[e];
+                }
+                if (!ok[e]) g0s[e] = g1s[e] = 0;
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (ok[e]) {
+                    const uint32_t g = g0s[e] + slot[e];
+                    gkey[g] = key[e];
+                    gidx[g] = (uint16_t)((tid + (e >> 2) * kThreads) * 4 + (e & 3));
                 }
             }
         }
@@ -154,33 +197,52 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
         STAMP(3);                                   // group
 
         // ---- rank = bucket base + #(smaller (key, socket) pairs in the bucket); CN-local id = rank / dc.
-        //      The thread's keys walk their buckets in one fused loop so that their LDS latencies overlap;
-        //      one 32-bit read per bucket-mate, the socket id only on a key tie.
+        //      Step k reads bucket-mate k of each of the thread's keys: the reads go out together (unconditionally, with
+        //      a harmless index when the bucket is exhausted), one wait per step; the socket id only on a key tie.
         uint16_t *wp = win + (size_t)(p % dv) * S;
         {
-            uint32_t rank[KMAX * 4], span = 0;
+            constexpr int E = KMAX * 4;
+            uint32_t rank[E], span = 0;
 #pragma unroll
-            for (int e = 0; e < KMAX * 4; e++) {
-                const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
-                rank[e] = g0s[e];
-                if (s < S) span = max(span, g1s[e] - g0s[e]); else g1s[e] = g0s[e] = 0;
-            }
+            for (int e = 0; e < E; e++) { rank[e] = g0s[e]; span = max(span, g1s[e] - g0s[e]); }
             for (uint32_t step = 0; step < span; step++) {
+                uint32_t k2[E];
+                bool on[E], tie = false;
 #pragma unroll
-                for (int e = 0; e < KMAX * 4; e++) {
+                for (int e = 0; e < E; e++) {
                     const uint32_t g = g0s[e] + step;
-                    if (g < g1s[e] && step != slot[e]) {            // slot[e] is this key's own place in the bucket
-                        const uint32_t k2 = gkey[g];
-                        const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
-                        rank[e] += (k2 < key[e]) || (k2 == key[e] && gidx[g] < (uint16_t)s);
-                    }
+                    on[e] = g < g1s[e] && step != slot[e];          // slot[e] is this key's own place in the bucket
+                    k2[e] = gkey[on[e] ? g : 0u];
+                }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    rank[e] += on[e] && k2[e] < key[e];
+                    tie |= on[e] && k2[e] == key[e];
+                }
+                if (tie) {
+#pragma unroll
+                    for (int e = 0; e < E; e++)
+                        if (on[e] && k2[e] == key[e])
+                            rank[e] += gidx[g0s[e] + step] < (uint16_t)((tid + (e >> 2) * kThreads) * 4 + (e & 3));
                 }
             }
 #pragma unroll
-            for (int e = 0; e < KMAX * 4; e++) {
-                const int s = (tid + (e >> 2) * kThreads) * 4 + (e & 3);
-                if (ENS == 2) { if (s < S) wp[s] = (uint16_t)(rank[e] - (uint32_t)((s / a.cns_pos) * a.cns_pos)); }
-                else if (s < S) wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank[e] >> a.dc_shift : rank[e] / (uint32_t)a.dc);
+            for (int k = 0; k < KMAX; k++) {
+                const int q = tid + k * kThreads, s0 = q * 4;
+                uint32_t id[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t r = rank[k * 4 + u];
+                    if (ENS == 2) id[u] = r - (uint32_t)(((s0 + u) / a.cns_pos) * a.cns_pos);
+                    else          id[u] = a.dc_shift >= 0 ? r >> a.dc_shift : r / (uint32_t)a.dc;
+                }
+                if (q < ncalls && s0 + 3 < S && (S & 3) == 0) {     // the usual case: one 8-byte store for 4 sockets
+                    uint2 v; v.x = id[0] | (id[1] << 16); v.y = id[2] | (id[3] << 16);
+                    *reinterpret_cast<uint2 *>(wp + s0) = v;
+                } else if (q < ncalls) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (s0 + u < S) wp[s0 + u] = (uint16_t)id[u];
+                }
             }
         }
         __syncthreads();
@@ -451,15 +513,16 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
     const int rows = a.nb / kThreads;                               // 1, 2, 4 or 8 rows of 64 per wave
     void (*kern)(const SArgs) = nullptr;
     if (ensemble == SCLDPC_ENS_PROTOGRAPH) {
-        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 2> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 2>
-                                                                                          : sample_philox_kernel<1, 4, ADJ16, 2>;
-        else           kern = sample_philox_kernel<2, 8, ADJ16, 2>;
-        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 2>;
+        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 2, false> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 2, false>
+                                                                                          : sample_philox_kernel<1, 4, ADJ16, 2, false>;
+        else           kern = sample_philox_kernel<2, 8, ADJ16, 2, false>;
+        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 2, false>;
     } else {
-        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 0> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 0>
-                                                                                          : sample_philox_kernel<1, 4, ADJ16, 0>;
-        else           kern = sample_philox_kernel<2, 8, ADJ16, 0>;
-        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 0>;
+        // byte-wide bucket counters (FINE) for the chain ensembles
+        if (kmax == 1) kern = rows == 1 ? sample_philox_kernel<1, 1, ADJ16, 0, true> : rows == 2 ? sample_philox_kernel<1, 2, ADJ16, 0, true>
+                                                                                                : sample_philox_kernel<1, 4, ADJ16, 0, true>;
+        else           kern = sample_philox_kernel<2, 8, ADJ16, 0, true>;
+        if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 0, true>;
     }
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
