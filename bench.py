@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="trials per GPU per step")
+    ap.add_argument("--batch", type=int, default=16384, help="trials per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
     ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")

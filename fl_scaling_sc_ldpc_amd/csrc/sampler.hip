@@ -63,8 +63,11 @@ using scldpc_dev::wave_inclusive_scan;
 // bucket holds 0.24 keys on average instead of 1 and the ranking loop below runs ~3 steps per wave instead of ~7.  After the
 // scan a word holds [exclusive prefix:14 | c0:4 | c1:4 | c2:4 | c3:4].  A bucket with 16 keys (never, for Philox keys: the
 // mean is 0.24) traps instead of corrupting its neighbour.
+// Two of these 1024-thread workgroups share a CU only if a wave's SGPR allocation lets 8 waves sit on a SIMD: the 800-entry
+// scalar file admits ⌊800 / (⌈sgpr/16⌉·16 + 16)⌋ waves, i.e. at most 80 SGPRs per wave.  Left alone the compiler takes 106
+// (one workgroup per CU, half the throughput); capped, the few extra uniforms live in VGPR lanes.
 template <int KMAX, int ROWS, bool ADJ16, int ENS, bool FINE>
-__global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_kernel(const SArgs a)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                           // nb counters → per-slice exclusive prefix
@@ -81,10 +84,10 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
     const int kshift = FINE ? a.shift - 2 : a.shift;                // key >> kshift = bucket
 
     STAMP_DECL
+    for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
+    __syncthreads();
     for (int p = 0; p < a.D; p++) {
-        for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
-        __syncthreads();
-        STAMP(0);                                   // clear
+        STAMP(0);                                   // (emit of the previous position)
 
         // ---- keys + bucket histogram; the atomic's return value is the arrival slot in the bucket
         uint32_t key[KMAX * 4], slot[KMAX * 4], crowded = 0;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
             }
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                if (ok[e]) {
+                if (ok[e] && g1s[e] - g0s[e] > 1u) {                // a key alone in its bucket has rank g0: nothing to compare
                     const uint32_t g = g0s[e] + slot[e];
                     gkey[g] = key[e];
                     gidx[g] = (uint16_t)((tid + (e >> 2) * kThreads) * 4 + (e & 3));
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(kThreads) void sample_philox_kernel(const SArgs a)
         //      Step k reads bucket-mate k of each of the thread's keys: the reads go out together (unconditionally, with
         //      a harmless index when the bucket is exhausted), one wait per step; the socket id only on a key tie.
         uint16_t *wp = win + (size_t)(p % dv) * S;
+        for (int b = tid; b < nb; b += kThreads) hist[b] = 0;        // the counters are dead: clear them for the next position
         {
             constexpr int E = KMAX * 4;
             uint32_t rank[E], span = 0;
