@@ -28,7 +28,7 @@ def short(name):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384      # bench.py's default batch
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
