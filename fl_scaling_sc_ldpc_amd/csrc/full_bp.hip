@@ -13,7 +13,7 @@
 // Two CN-word layouts:
 //   Wide   32 bit  [cnt:4 | deg:4 | Σ global VN id:24]   any ensemble that fits; needed for trajectories (deg)
 //   Packed 16 bit  [cnt:4 | ⊕ local VN id:12]            when dv·vns_pos <= 4096 (local id = edge·vns_pos + t):
-//                  half the LDS ⇒ two 512-thread workgroups per CU hide each other's HBM latency.
+//                  half the LDS ⇒ two 1024-thread workgroups per CU hide each other's latencies.
 //
 // Iteration t of the reference == one frontier round (one barrier):
 //   every CN with cnt == 1 at the start of the round releases its VN; the releasing thread fetches the
@@ -139,7 +139,9 @@ struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of wo
 };
 
 template <class ST, bool TRAJ, int DV, bool A16, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void full_bp_kernel(const Args a)
+// Two 1024-thread workgroups per CU = 8 waves per SIMD, which the scalar file admits only up to 80 SGPRs per wave
+// (⌊800 / (⌈sgpr/16⌉·16 + 16)⌋ waves): capped here, the overflow lives in VGPR lanes.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void full_bp_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
     const int trial = blockIdx.x;
@@ -475,7 +477,7 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     const bool d4 = p->dv == 4;
 #define PICK(ST, TRAJ, BLK) (d4 ? (adj16 ? full_bp_kernel<ST, TRAJ, 4, true, BLK> : full_bp_kernel<ST, TRAJ, 4, false, BLK>) \
                                 : (adj16 ? full_bp_kernel<ST, TRAJ, 0, true, BLK> : full_bp_kernel<ST, TRAJ, 0, false, BLK>))
-    if (packed) { block = 512; kern = PICK(Packed, false, 512); }
+    if (packed) kern = PICK(Packed, false, 1024);
     else if (global_ws) kern = traj ? PICK(WideG, true, 1024) : PICK(WideG, false, 1024);
     else if (traj) kern = PICK(Wide, true, 1024);
     else kern = PICK(Wide, false, 1024);
