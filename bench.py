@@ -92,7 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384, help="trials per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
+    ap.add_argument("--overlap", action="store_true",
+                    help="two streams: the sampler of step k+1 beside the decoder of step k (default: one stream)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default) one stream: sample, then decode, then accumulate")
     ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")
     a = ap.parse_args()
 
@@ -113,8 +115,9 @@ def main():
     from fl_scaling_sc_ldpc_amd import engine as E
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch
-    # Two (adjacency, channel, counters) buffers and two streams: the sampler of step k+1 runs beside the decoder of
-    # step k (the first is LDS/VALU-heavy, the second waits on memory most of the time, so they share a CU well).
+    # One stream by default.  --overlap: two (adjacency, channel, counters) buffers and two streams, the sampler of step
+    # k+1 beside the decoder of step k — worth +1 % now that each kernel fills a CU's wave slots on its own.
+    a.no_overlap = not a.overlap
     nbuf = 1 if a.no_overlap else 2
     d_adj = [torch.empty((B, p.n, p.dv), dtype=torch.int32 if a.adj32 else torch.int16, device=dev) for _ in range(nbuf)]
     d_ch = [torch.empty((B, p.nw), dtype=torch.int32, device=dev) for _ in range(nbuf)]
