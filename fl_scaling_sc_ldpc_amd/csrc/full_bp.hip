@@ -454,9 +454,15 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     // two workgroups per CU with the packed CN words when the ensemble allows it (and no trajectory rows)
     const bool packed = !traj && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
     bool global_ws = false;
-    if (!packed && make_layout<Wide>(p, scldpc::kMaxLdsBytes, &a.lay)) {
+    // Wide words: two workgroups per CU when everything (with queues of >= 1024 entries) fits half the LDS, else one
+    auto fits = [&](auto tag, Layout *lay) {
+        using ST = decltype(tag);
+        if (make_layout<ST>(p, scldpc::kMaxLdsBytes / 2 - 1024, lay) == 0 && lay->qcap >= 1024) return true;
+        return make_layout<ST>(p, scldpc::kMaxLdsBytes, lay) == 0;
+    };
+    if (!packed && !fits(Wide{}, &a.lay)) {
         // CN words to a global workspace; the VN bitmap, scan bitmap and queues must still fit the LDS
-        if (make_layout<WideG>(p, scldpc::kMaxLdsBytes, &a.lay))
+        if (!fits(WideG{}, &a.lay))
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                      "scldpc_full_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
         global_ws = true;

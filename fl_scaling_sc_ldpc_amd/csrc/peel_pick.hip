@@ -20,17 +20,18 @@ namespace {
 
 using namespace scldpc_dev;
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 64;
 
 struct Args {
     int dv, vns_pos, cns_pos, n, ncn, total_size, steps, nw, nd1;     // nd1 = 64-bit words of the degree-1 bitmap
     int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
     uint32_t magic_v, seed_lo, seed_hi;
     unsigned long long trial0;
-    int off_d1, off_blk, off_mt, off_u, off_sc;   // LDS offsets (32-bit words) behind the CN words
+    int off_d1, off_blk, off_mt, off_sc;   // LDS offsets (32-bit words) behind the CN words
     const void *vn_adj;
     const uint32_t *chan;
     uint32_t *ws;                   // [T][ncn] CN words in global memory (G only)
+    unsigned long long *ws_d1;      // [T][nd1] degree-1 bitmaps in global memory (D1G)
     unsigned long long *moments;    // optional [3][steps+1]: #(r1 != 0), Σ r1, Σ r1² over the trials (atomic adds)
     uint32_t *mt;                   // [T][625]: 624 state words + index
     int32_t *r1;                    // [T][steps+1] or null
@@ -51,7 +52,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. the notebook's N = 10000)
-template <int DV, bool A16, bool G>
+template <int DV, bool A16, bool G, bool D1G>
 __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
@@ -63,9 +64,11 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         else             return cn[c];
     };
     int *blk = reinterpret_cast<int *>(lds + a.off_blk);                  // #degree-1 CNs per block of 64 bitmap words
-    unsigned long long *d1 = reinterpret_cast<unsigned long long *>(lds + a.off_d1);   // nd1 words of 64 bits
+    // the degree-1 bitmap: nd1 words of 64 bits, in LDS or (D1G) behind the trial's CN words in the workspace
+    unsigned long long *d1;
+    if constexpr (D1G) d1 = a.ws_d1 + (size_t)blockIdx.x * a.nd1;
+    else               d1 = reinterpret_cast<unsigned long long *>(lds + a.off_d1);
     uint32_t *mt = lds + a.off_mt;                                        // 624 words
-    uint32_t *U = lds + a.off_u;                                          // channel bits (build only)
     int *sc = reinterpret_cast<int *>(lds + a.off_sc);                   // [0] #erased, [1] r1[0]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
     for (int w = tid; w < a.nw; w += kBlock) {
         uint32_t x = a.chan[(size_t)trial * a.nw + w];
         if (w == a.nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
-        U[w] = x;
         ne_local += __popc(x);
     }
     if (a.rng_mode == 0)
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         if (lane == 63 && tot) atomicAdd(&sc[0], (int)tot);
     }
     for (int j = tid; j < n; j += kBlock) {
-        if ((U[j >> 5] >> (j & 31)) & 1u) {
+        if ((a.chan[(size_t)trial * a.nw + (j >> 5)] >> (j & 31)) & 1u) {      // (j < n: no padding bit is ever tested)
             int32_t cc[8];
             load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
             for (int i = 0; i < dv; i++) atomicAdd(&cn[cc[i]], kCntOne + (uint32_t)j);
@@ -169,7 +171,11 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         const int B0 = __ffsll((long long)__ballot(binc > x)) - 1;
         uint32_t r = x - (uint32_t)__builtin_amdgcn_readlane((int)(binc - bc), B0);
         const int widx = B0 * 64 + lane;
-        const unsigned long long word = widx < a.nd1 ? d1[widx] : 0ull;
+        unsigned long long word = 0ull;
+        if (widx < a.nd1) {
+            if constexpr (D1G) word = __hip_atomic_load(&d1[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else               word = d1[widx];
+        }
         const uint32_t wc = (uint32_t)__popcll(word);
         const uint32_t winc = wave_inclusive_scan(wc);
         const int W0 = __ffsll((long long)__ballot(winc > r)) - 1;
@@ -251,35 +257,38 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
     }
     if (a.nd1 > 4096)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: more than 262144 pickable CNs");
-    bool gws = false;
-    size_t lds_bytes = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        gws = pass == 1;
-        int off = gws ? 0 : (ncn + 3) & ~3;
-        a.off_d1 = off; off += (2 * a.nd1 + 3) & ~3;
+    // One wave steps one trial through a chain of dependent picks, so throughput = trials in flight.  A workgroup is one
+    // wave (up to 32 per CU); what it keeps in LDS decides how many fit: the CN words go to the workspace unless the
+    // LDS-resident layout already allows 16 workgroups per CU, and so does the degree-1 bitmap when it is the next obstacle.
+    auto layout = [&](bool cn_global, bool d1_global) {
+        int off = cn_global ? 0 : (ncn + 3) & ~3;
+        a.off_d1 = off; off += d1_global ? 0 : (2 * a.nd1 + 3) & ~3;
         a.off_blk = off; off += 64;
-        a.off_mt = off; off += 624;
-        a.off_u = off;  off += (a.nw + 3) & ~3;
+        a.off_mt = off; off += a.rng_mode == 0 ? 624 : 0;
         a.off_sc = off; off += 4;
-        lds_bytes = 4u * (size_t)off;
-        // keep a few trials per CU in flight when the CN words are in the workspace
-        if (lds_bytes + 64 <= (size_t)scldpc::kMaxLdsBytes) break;
-        if (gws)
-            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                     "scldpc_peel_pick_device: bitmaps of %d CNs / %d VNs do not fit 160 KiB of LDS", ncn, n);
-    }
+        return 4u * (size_t)off;
+    };
+    const size_t want = (size_t)scldpc::kMaxLdsBytes / 16;
+    bool gws = false, d1g = false;
+    size_t lds_bytes = layout(false, false);
+    if (lds_bytes > want) { gws = true; lds_bytes = layout(true, false); }
+    if (gws && lds_bytes > want) { d1g = true; lds_bytes = layout(true, true); }
+    if (lds_bytes + 64 > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: needs %zu B of LDS", lds_bytes);
     if (gws) {
+        const size_t cn_bytes = (((size_t)ntrials * ncn * sizeof(uint32_t)) + 255) & ~(size_t)255;
         void *ws = nullptr;
-        if (int rc = scldpc::workspace((size_t)ntrials * ncn * sizeof(uint32_t), &ws)) return rc;
+        if (int rc = scldpc::workspace(cn_bytes + (d1g ? (size_t)ntrials * a.nd1 * 8 : 0), &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
+        a.ws_d1 = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + cn_bytes);
     }
     a.moments = reinterpret_cast<unsigned long long *>(d_moments);
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.mt = d_mt_state; a.r1 = d_r1; a.out = d_out;
     void (*kern)(const Args);
-    if (gws) kern = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true, true> : peel_pick_kernel<4, false, true>)
-                               : (adj16 ? peel_pick_kernel<0, true, true> : peel_pick_kernel<0, false, true>);
-    else     kern = p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true, false> : peel_pick_kernel<4, false, false>)
-                               : (adj16 ? peel_pick_kernel<0, true, false> : peel_pick_kernel<0, false, false>);
+#define PICK(G, D) (p->dv == 4 ? (adj16 ? peel_pick_kernel<4, true, G, D> : peel_pick_kernel<4, false, G, D>) \
+                               : (adj16 ? peel_pick_kernel<0, true, G, D> : peel_pick_kernel<0, false, G, D>))
+    kern = d1g ? PICK(true, true) : gws ? PICK(true, false) : PICK(false, false);
+#undef PICK
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);

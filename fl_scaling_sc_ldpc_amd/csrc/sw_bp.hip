@@ -42,7 +42,7 @@ struct Args {
 
 // G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. L=100, N=2000) instead of LDS
 template <int DV, bool A16, bool G>
-__global__ __launch_bounds__(kBlock) void sw_bp_kernel(const Args a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void sw_bp_kernel(const Args a)   // see full_bp.hip
 {
     extern __shared__ uint32_t lds[];
     uint32_t *cn_state;
@@ -247,7 +247,13 @@ int make_layout(const scldpc_code_params *p, int W, bool global_ws, Layout *lay)
     lay->pos_cnt = take(p->L);
     lay->pos_ss = take(p->L);
     lay->scal = take(S_NSCAL);
-    const int left = scldpc::kMaxLdsBytes / 4 - off;
+    // Two workgroups per CU (half the LDS each) whenever queues of at least 1024 entries still fit: the kernel waits on
+    // LDS / L2 round trips most of the time and a second trial on the CU hides them.  Otherwise the whole LDS.
+    int left = scldpc::kMaxLdsBytes / 4 - off;
+    {
+        const int half = scldpc::kMaxLdsBytes / 8 - 256 - off;
+        if (half >= 2 * 1024) left = half;
+    }
     int qcap = (left / 2) & ~3;
     if (qcap > 8192) qcap = 8192;
     if (qcap < 64) return -1;

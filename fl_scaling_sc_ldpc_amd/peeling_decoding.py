@@ -200,7 +200,7 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
 
 
 def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_protograph, num_repeats=None,
-                                  doping_points=[], rng="numpy", seed=0, batch=256, device="cuda:0",
+                                  doping_points=[], rng="numpy", seed=0, batch=None, device="cuda:0",
                                   want_moments=False):
     """Random-pick peeling with the degree-1-CN trajectory (PD:705-789): returns (None, r1, plrs) with
     r1 int64 [num_repeats, num_pd_steps+1] and plrs float64 [num_repeats].  want_moments=True (philox mode) returns
@@ -237,6 +237,10 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
         raise ValueError("rng must be 'numpy' or 'philox'")
     r1_all = None if want_moments else np.zeros((num_repeats, num_pd_steps + 1), dtype="int")
     moments = None
+    if batch is None:
+        # one wave steps one trial: the kernel wants ~8192 trials in flight; stay below ~16 GB of device buffers
+        per_trial = L * M * l_deg * 4 + (0 if want_moments else 4 * (num_pd_steps + 1))
+        batch = max(256, min(8192, int(16e9 // per_trial)))
     for done in range(0, num_repeats, batch):
         nb = min(batch, num_repeats - done)
         d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device,

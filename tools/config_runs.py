@@ -24,7 +24,7 @@ def timed(label, fn, trials):
 
 # C2: (4,8) L=50 N=1000 full BP — bench.py.  Here: limited iterations and the trajectory mode.
 p = E.make_params(4, 8, 50, 1000)
-T = 4096
+T = 8192
 d_adj, d_ch = E.sample_philox(p, 1, 0, T, 0.48, adj16=True)
 timed("C2  full BP, unlimited (decode only)", lambda: E.full_bp(p, d_adj, d_ch), T)
 timed("C2  full BP, max 100 iterations", lambda: E.full_bp(p, d_adj, d_ch, max_it=100), T)
@@ -33,7 +33,7 @@ timed("C2  square window W=20, 6/60 iterations", lambda: E.sw_bp(p, d_adj, d_ch,
 g = PD._Geometry(4, 8, 50, 1000, True, True, [])
 timed("C1  sweep peeling + stopping sets (simulate_sc_ldpc)", lambda: E.peel_sweep(g.params, d_adj, d_ch, g.total_size), T)
 steps = int(1000 * 50 * 0.58)
-Tp = 1024
+Tp = T          # one wave per trial: the kernel wants thousands of trials in flight
 timed("C1  random-pick peeling, N=1000, 29000 steps (simulate_peeling_decoder_ldpc)",
       lambda: E.peel_pick(p, d_adj[:Tp], d_ch[:Tp], 500 * 50, steps, seed=3, want_r1=True), Tp)
 del d_adj, d_ch
@@ -47,13 +47,13 @@ del a4, c4
 
 # C3: (4,8) L=50 N=10000 random-pick peeling, non-terminated, moments only
 p3 = E.make_params(4, 8, 50, 10000)
-T3 = 512
+T3 = 4096
 a3, c3 = timed("C3  sampling L=50 N=10000 (big-ensemble sampler)", lambda: E.sample_philox(p3, 1, 0, T3, 0.48, adj16=True), T3)
 steps3 = int(10000 * 50 * 0.58)
 mom = torch.zeros((3, steps3 + 1), dtype=torch.int64, device="cuda")
 timed("C3  random-pick peeling N=10000, 290000 steps, in-kernel moments",
       lambda: E.peel_pick(p3, a3, c3, 5000 * 50, steps3, seed=3, want_r1=False, moments=mom), T3)
-timed("C3  full BP N=10000 (workspace)", lambda: E.full_bp(p3, a3, c3), T3)
+timed("C3  full BP N=10000 (workspace)", lambda: E.full_bp(p3, a3[:512], c3[:512]), 512)
 
 # C5: doped (4,8) streaming ensemble N=5000, buffer L=50, W=20, doping {10,11,12}
 p5 = E.make_params(4, 8, 50, 5000)
