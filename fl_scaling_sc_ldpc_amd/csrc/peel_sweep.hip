@@ -293,7 +293,10 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
         a.lay.frozen = take(((ncn + 63) / 64) * 2);
         a.lay.pos_flag = take(p->L + p->dv);
         a.lay.scal = take(S_NSCAL);
-        qcap = ((scldpc::kMaxLdsBytes / 4 - off) / 2) & ~3;
+        // two workgroups per CU (half the LDS each) when queues of >= 1024 entries still fit, else the whole LDS
+        int left = scldpc::kMaxLdsBytes / 4 - off;
+        if (scldpc::kMaxLdsBytes / 8 - 256 - off >= 2 * 1024) left = scldpc::kMaxLdsBytes / 8 - 256 - off;
+        qcap = (left / 2) & ~3;
         if (qcap > 8192) qcap = 8192;
         if (qcap >= 256) break;
         if (global_ws)

@@ -200,6 +200,26 @@ def test_peel_pick_beyond_the_lds_budget(PD, oracle, L, M, e, term):
     assert (mom[0] == (r1 != 0).sum(0)).all() and (mom[1] == r1.sum(0)).all() and (mom[2] == (r1 ** 2).sum(0)).all()
 
 
+def test_peel_pick_with_the_degree1_bitmap_in_the_workspace(PD, oracle):
+    """More than ~77 000 pickable CNs: the degree-1 bitmap leaves the LDS too (one small single-wave workgroup per
+    trial); few erasures keep the CPU twin's run short.  Philox picks and the exact MT19937 stream."""
+    from oracle import pd_oracle as P
+    E = PD.E
+    L, M, e, T = 44, 4000, 0.04, 2
+    none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, True, False, T, [], rng="philox", seed=12)
+    p = E.CodeParams(4, 8, L, M // 2, M)
+    d_adj, d_ch = E.sample_philox(p, 12, 0, T, e, adj16=True)
+    A = E.adj16_to_global(p, d_adj.cpu().numpy()).astype(np.int64)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n).astype(bool)
+    for t in range(T):
+        ref_r1, ref_plr = P.random_pick_trial(A[t], bits[t], 4, 8, L, M, e, True, P.PhiloxPickStream(12, t))
+        assert (r1[t] == ref_r1).all() and plrs[t] == ref_plr
+    np.random.seed(33); random.seed(33)
+    _, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, True, False, 1, [])
+    ref_r1, ref_plr = P.simulate_peeling_decoder_ldpc(33, e, 4, 8, L, M, True, 1)
+    assert (r1 == ref_r1).all() and (plrs == ref_plr).all()
+
+
 def test_peel_pick_notebook_size_exact_stream(PD):
     """M = 10000 (the notebook's trajectory size, PD:1216) on a short chain, with the reference's own numpy + `random`
     streams: the device consumes the MT19937 state exactly as random.choice would."""
