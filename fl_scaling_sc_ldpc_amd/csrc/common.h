@@ -22,6 +22,17 @@ int check_params(const scldpc_code_params *p);
 // slot 0: CN words of the decoders; slot 1: the big-ensemble sampler's scratch (the two may run on different streams).
 int workspace(size_t bytes, void **out, int slot = 0);
 
+// x / d == umulhi(x, magic) for every x < limit?  (monotone step function: checking the steps suffices)
+inline bool magic_of(int d, int64_t limit, uint32_t *magic)
+{
+    *magic = (uint32_t)((1ull << 32) / (uint32_t)d) + 1u;
+    for (int64_t q = 0; q * d < limit + d; q++) {
+        const uint64_t x0 = (uint64_t)q * d, x1 = x0 ? x0 - 1 : 0;
+        if (((x0 * *magic) >> 32) != (uint64_t)q || ((x1 * *magic) >> 32) != x1 / (uint64_t)d) return false;
+    }
+    return true;
+}
+
 constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
 #define SCLDPC_HIP_CHECK(expr)                                                                     \

@@ -23,6 +23,7 @@
 // belongs to such a pair iff every one of its CNs has cnt == 2 and the same partner, in a's position.
 #include "common.h"
 #include "kernel_util.h"
+#include "cn_words.h"
 
 namespace {
 
@@ -36,9 +37,8 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
     int qcap, nw;
 };
 
-struct Args {
-    int dv, L, vns_pos, cns_pos, n, nk, cn_lim, max_it, rows_cap;
-    uint32_t magic_v, magic_c;      // floor(2^32/d)+1: x/d == umulhi(x, magic) for the ranges used here
+struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
+    int dv, L, cns_pos, n, nk, cn_lim, max_it, rows_cap;
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     uint32_t *ws;                   // [T][nk] CN words in global memory (WideG only)
@@ -46,96 +46,6 @@ struct Args {
     int32_t *counters;
     int32_t *rows;
     uint32_t *erased_out;
-};
-
-struct Vn { int j, pos, t; };
-
-// ---- CN-word policies --------------------------------------------------------------------------
-// G = false: the words live in LDS.  G = true: they live in a global-memory workspace (one nk-word slice per trial,
-// L2-resident while hot) for ensembles whose CN words exceed the LDS — N >= 2500 at (4,8), e.g. bp_traj's shipped
-// Def_M = 2500.  Same algorithm with global atomics; plain reads go past the CU's L1 (agent-scope loads) so that they
-// see what the atomics did in L2.  U, the frontier queues and the scan bitmap stay in LDS either way.
-template <bool G>
-struct WideT {
-    static constexpr bool kGlobal = G;
-    static __host__ __device__ int lds_words(int nk) { return G ? 0 : nk; }
-    static __host__ __device__ int words(int nk) { return nk; }
-    static __device__ __forceinline__ uint32_t ld(const uint32_t *st, int c)
-    {
-        if constexpr (G) return __hip_atomic_load(&st[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else             return st[c];
-    }
-    static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int, int, bool erased, bool deg)
-    {
-        atomicAdd(&st[c], (deg ? kDegOne : 0u) + (erased ? kCntOne + (uint32_t)v.j : 0u));
-    }
-    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return ld(st, c) >> kCntShift; }
-    static __device__ __forceinline__ uint32_t deg(const uint32_t *st, int c) { return (ld(st, c) >> kDegShift) & kDegMask; }
-    // the single erased neighbour of c (valid only if cnt == 1 in the word that was read); -1 otherwise
-    static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &)
-    {
-        const uint32_t w = ld(st, c);
-        return (w >> kCntShift) == 1u ? (int)(w & kSumMask) : -1;
-    }
-    static __device__ __forceinline__ uint32_t remove_cnt(uint32_t *st, int c, const Vn &v, int, int)   // returns old cnt
-    {
-        return atomicSub(&st[c], kCntOne + (uint32_t)v.j) >> kCntShift;
-    }
-    static __device__ __forceinline__ void remove_fold(uint32_t *, int, const Vn &, int, int) {}
-    // partner of v at CN c if cnt == 2, else -1
-    static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int, const Args &)
-    {
-        const uint32_t w = ld(st, c);
-        return (w >> kCntShift) == 2u ? (int)((w & kSumMask) - (uint32_t)v.j) : -1;
-    }
-};
-using Wide = WideT<false>;
-using WideG = WideT<true>;
-
-struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of word c >> 1
-    static constexpr bool kGlobal = false;
-    static __host__ __device__ int lds_words(int nk) { return (nk + 1) / 2; }
-    static __host__ __device__ int words(int nk) { return (nk + 1) / 2; }
-    static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int i, int V, bool erased, bool)
-    {
-        if (!erased) return;
-        const int sh = (c & 1) * 16;
-        atomicAdd(&st[c >> 1], 0x1000u << sh);
-        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << sh);
-    }
-    static __device__ __forceinline__ uint32_t half(const uint32_t *st, int c) { return (st[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu; }
-    static __device__ __forceinline__ uint32_t cnt(const uint32_t *st, int c) { return half(st, c) >> 12; }
-    static __device__ __forceinline__ uint32_t deg(const uint32_t *, int) { return 0; }
-    static __device__ __forceinline__ int lid_to_vn(int c, uint32_t lid, const Args &a)
-    {
-        const int V = a.vns_pos;
-        int i = 0;
-        while ((i + 1) * V <= (int)lid) i++;                         // < dv steps
-        const int pos_c = (int)__umulhi((uint32_t)c, a.magic_c);
-        return (pos_c - i) * V + ((int)lid - i * V);
-    }
-    static __device__ __forceinline__ int lone_vn(const uint32_t *st, int c, const Args &a)
-    {
-        // cnt and fold are updated by two atomics (count first, fold second).  The only update a
-        // CN of the CURRENT frontier can see in its round is the removal of its own VN, which drops cnt to 0
-        // before it touches the fold — so a frontier CN read with cnt == 1 carries exactly its one neighbour.
-        const uint32_t h = half(st, c);
-        return (h >> 12) == 1u ? lid_to_vn(c, h & 0xFFFu, a) : -1;
-    }
-    static __device__ __forceinline__ uint32_t remove_cnt(uint32_t *st, int c, const Vn &, int, int)
-    {
-        const int sh = (c & 1) * 16;
-        return (atomicSub(&st[c >> 1], 0x1000u << sh) >> (sh + 12)) & 0xFu;
-    }
-    static __device__ __forceinline__ void remove_fold(uint32_t *st, int c, const Vn &v, int i, int V)
-    {
-        atomicXor(&st[c >> 1], (uint32_t)(i * V + v.t) << ((c & 1) * 16));
-    }
-    static __device__ __forceinline__ int partner(const uint32_t *st, int c, const Vn &v, int i, const Args &a)
-    {
-        const uint32_t h = half(st, c);
-        return (h >> 12) == 2u ? lid_to_vn(c, (h & 0xFFFu) ^ (uint32_t)(i * a.vns_pos + v.t), a) : -1;
-    }
 };
 
 template <class ST, bool TRAJ, int DV, bool A16, int BLOCK>
@@ -410,17 +320,6 @@ bool packed_ok(const scldpc_code_params *p)
     return (int64_t)p->dv * p->vns_pos <= 4096 && p->dc <= 15 && p->dv <= 8;
 }
 
-// x / d == umulhi(x, magic) for every x < limit?  (monotone step function: checking the steps suffices)
-bool magic_of(int d, int64_t limit, uint32_t *magic)
-{
-    *magic = (uint32_t)((1ull << 32) / (uint32_t)d) + 1u;
-    for (int64_t q = 0; q * d < limit + d; q++) {
-        const uint64_t x0 = (uint64_t)q * d, x1 = x0 ? x0 - 1 : 0;
-        if (((x0 * *magic) >> 32) != (uint64_t)q || ((x1 * *magic) >> 32) != x1 / (uint64_t)d) return false;
-    }
-    return true;
-}
-
 }  // namespace
 
 extern "C" int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p)
@@ -473,7 +372,7 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.cn_lim = is_term ? nk : p->L * p->cns_pos;                    // BPT:944-948
     a.max_it = max_it; a.rows_cap = traj ? rows_cap : 0;
-    if (!magic_of(p->vns_pos, n, &a.magic_v) || !magic_of(p->cns_pos, nk, &a.magic_c))
+    if (!scldpc::magic_of(p->vns_pos, n, &a.magic_v) || !scldpc::magic_of(p->cns_pos, nk, &a.magic_c))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_full_bp_device: reciprocal division inexact for this size");
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.rows = d_rows;
     a.erased_out = d_erased_bits;

@@ -15,6 +15,7 @@
 // The frontier is found by a scan of Cw when a window opens and kept in an LDS queue afterwards.
 #include "common.h"
 #include "kernel_util.h"
+#include "cn_words.h"
 
 namespace {
 
@@ -29,8 +30,8 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
     int qcap, nw;
 };
 
-struct Args {
-    int dv, L, vns_pos, cns_pos, n, nk, W, max_it, init_it;
+struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
+    int dv, L, cns_pos, n, nk, W, max_it, init_it;
     int classical;                  // 0: square window (BPW:628-912); 1: classical window (BPF:627-897)
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
@@ -40,18 +41,15 @@ struct Args {
     uint32_t *erased_out;
 };
 
-// G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. L=100, N=2000) instead of LDS
-template <int DV, bool A16, bool G>
+// ST: CN-word policy (cn_words.h) — Packed (16 bit, two workgroups per CU), Wide (LDS) or WideG (global workspace, for
+// ensembles beyond the LDS budget, e.g. L=100, N=2000)
+template <int DV, bool A16, class ST>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void sw_bp_kernel(const Args a)   // see full_bp.hip
 {
     extern __shared__ uint32_t lds[];
     uint32_t *cn_state;
-    if constexpr (G) cn_state = a.ws + (size_t)blockIdx.x * a.nk;
-    else             cn_state = lds + a.lay.cn_state;
-    auto ldw = [&](int c) -> uint32_t {      // reads past the CU's L1 when the words live in global memory
-        if constexpr (G) return __hip_atomic_load(&cn_state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else             return cn_state[c];
-    };
+    if constexpr (ST::kGlobal) cn_state = a.ws + (size_t)blockIdx.x * a.nk;
+    else                       cn_state = lds + a.lay.cn_state;
     uint32_t *S = lds + a.lay.S;
     uint32_t *fbits = lds + a.lay.fbits;
     uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
@@ -66,7 +64,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
     const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
     const uint32_t *ch = a.chan + (size_t)trial * nw;
 
-    for (int c = tid; c < nk; c += kBlock) cn_state[c] = 0;
+    for (int c = tid; c < ST::words(nk); c += kBlock) cn_state[c] = 0;
+    auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
     for (int w = tid; w < nw; w += kBlock) {
         uint32_t x = ch[w];
         if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
@@ -96,7 +95,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
             if (j < n && er[u]) {
                 nch++;
                 atomicAdd(&pos_cnt[j / V], 1);
-                for (int i = 0; i < dv; i++) atomicAdd(&cn_state[c[u][i]], kCntOne + (uint32_t)j);
+                const Vn v = make_vn(j);
+                for (int i = 0; i < dv; i++) ST::add(cn_state, c[u][i], v, i, V, true, false);
             }
         }
     }
@@ -128,24 +128,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
             int *rem_cnt = &scal[S_REM + gen % 3];
             int removed = 0;
             auto release = [&](uint32_t c) {
-                const uint32_t w = ldw(c);
-                if ((w >> kCntShift) != 1u) return;                         // its VN went via another CN this round
-                const uint32_t j = w & kSumMask;
-                if ((int)j < jlo) return;                                   // frozen VN: stays erased for good
+                const int j = ST::lone_vn(cn_state, (int)c, a);
+                if (j < 0) return;                                          // its VN went via another CN this round
+                if (j < jlo) return;                                        // frozen VN: stays erased for good
                 const uint32_t bit = 1u << (j & 31);
                 const uint32_t old = atomicAnd(&S[j >> 5], ~bit);
                 if (!(old & bit)) return;
-                atomicSub(&pos_cnt[j / V], 1);
+                const Vn v = make_vn(j);
+                atomicSub(&pos_cnt[v.pos], 1);
                 removed++;
                 int32_t cc[8];
-                load_adj<DV, A16>(adj, dv, (int)j, (int)j / V, C, cc);
+                load_adj<DV, A16>(adj, dv, j, v.pos, C, cc);
+                uint32_t o[8];
+                for (int i = 0; i < dv; i++) o[i] = ST::remove_cnt(cn_state, cc[i], v, i, V);
+                for (int i = 0; i < dv; i++) ST::remove_fold(cn_state, cc[i], v, i, V);
                 for (int i = 0; i < dv; i++) {
                     const uint32_t c2 = (uint32_t)cc[i];
-                    const uint32_t o = atomicSub(&cn_state[c2], kCntOne + j);
                     // 2 → 1 inside the window: fires in the next iteration.  CNs right of the window
                     // are found by the scan of the first window that contains them; CNs left of it
                     // (classical window only: VNs of positions posW-ms..posW-1) never send again.
-                    if ((o >> kCntShift) == 2u && (int)c2 < c1 && (int)c2 >= c0) {
+                    if (o[i] == 2u && (int)c2 < c1 && (int)c2 >= c0) {
                         const int idx = atomicAdd(push_cnt, 1);
                         if (idx < qcap) qn[idx] = c2; else *push_ovf = 1;
                     }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
                 // promote CNs into the round's own frontier
                 for (int base = c0 & ~63; base < c1; base += kBlock) {
                     const int c = base + tid;
-                    const bool v = c >= c0 && c < c1 && (ldw(c) >> kCntShift) == 1u;
+                    const bool v = c >= c0 && c < c1 && ST::cnt(cn_state, c) == 1u;
                     const unsigned long long m = __ballot(v);
                     if (c - lane < c1) {
                         if (lane == 0) fbits[c >> 5] = (uint32_t)m;
@@ -198,14 +200,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
             int32_t cc[8];
             load_adj<DV, A16>(adj, dv, va, pos, C, cc);
             bool pair = true;
-            uint32_t partner = 0;
+            int partner = -1;
+            const Vn v = make_vn(va);
             for (int i = 0; i < dv; i++) {
-                const uint32_t s = ldw(cc[i]);
-                const uint32_t b2 = (s & kSumMask) - (uint32_t)va;
-                if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
+                const int b2 = ST::partner(cn_state, cc[i], v, i, a);
+                if (b2 < 0 || (i > 0 && b2 != partner)) { pair = false; break; }
                 partner = b2;
             }
-            if (pair && (int)partner / V == pos) atomicAdd(&pos_ss[pos], 1);
+            if (pair && partner / V == pos) atomicAdd(&pos_ss[pos], 1);
         }
     }
     __syncthreads();
@@ -235,13 +237,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
     }
 }
 
-int make_layout(const scldpc_code_params *p, int W, bool global_ws, Layout *lay)
+template <class ST>
+int make_layout(const scldpc_code_params *p, int W, Layout *lay)
 {
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
     lay->nw = (n + 31) / 32;
-    lay->cn_state = take(global_ws ? 0 : nk);
+    lay->cn_state = take(ST::lds_words(nk));
     lay->S = take(lay->nw);
     lay->fbits = take(((nk + 63) / 64) * 2);
     lay->pos_cnt = take(p->L);
@@ -281,9 +284,11 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
     Args a{};
+    // packed 16-bit CN words when the ensemble allows them (two workgroups per CU), else 32-bit words in LDS, else in the workspace
+    const bool packed = (int64_t)p->dv * p->vns_pos <= 4096 && make_layout<Packed>(p, W, &a.lay) == 0;
     bool gws = false;
-    if (make_layout(p, W, false, &a.lay)) {
-        if (make_layout(p, W, true, &a.lay))
+    if (!packed && make_layout<Wide>(p, W, &a.lay)) {
+        if (make_layout<WideG>(p, W, &a.lay))
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                      "scldpc_sw_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
         gws = true;
@@ -291,16 +296,18 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
         if (int rc = scldpc::workspace((size_t)ntrials * nk * sizeof(uint32_t), &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
     }
+    if (!scldpc::magic_of(p->vns_pos, n > 4096 ? n : 4096, &a.magic_v) || !scldpc::magic_of(p->cns_pos, nk, &a.magic_c))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: reciprocal division inexact for this size");
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.W = W; a.max_it = max_it; a.init_it = init_it ? init_it : max_it;     // BPW:2101-2102
     a.classical = classical ? 1 : 0;
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
 
     void (*kern)(const Args);
-    if (gws) kern = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true, true> : sw_bp_kernel<4, false, true>)
-                               : (adj16 ? sw_bp_kernel<0, true, true> : sw_bp_kernel<0, false, true>);
-    else     kern = p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true, false> : sw_bp_kernel<4, false, false>)
-                               : (adj16 ? sw_bp_kernel<0, true, false> : sw_bp_kernel<0, false, false>);
+#define PICK(ST) (p->dv == 4 ? (adj16 ? sw_bp_kernel<4, true, ST> : sw_bp_kernel<4, false, ST>) \
+                             : (adj16 ? sw_bp_kernel<0, true, ST> : sw_bp_kernel<0, false, ST>))
+    kern = packed ? PICK(Packed) : gws ? PICK(WideG) : PICK(Wide);
+#undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
