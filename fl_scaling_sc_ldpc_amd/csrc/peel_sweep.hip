@@ -12,10 +12,14 @@
 //   * extract_stopping_sets (PD:1077-1095) = connected components of `lost` through all shared CNs; "expurgated"
 //     statistics ignore components of <= 2 VNs (PD:677-691): #lost_exp, and the number of distinct chain positions
 //     int(birthday / cns_per_pos) among the VNs of larger components.
-// Components are found by a lock-free union–find over the CNs (every lost VN unites its dv CNs), reusing the LDS
-// words of the CN state once peeling is done: [size saturating at 3 : 2 | parent : 30].
+// Only "is this VN's component larger than 2" is ever asked, and that is a local question: once peeling is done the CN
+// words are rebuilt over the LOST VNs alone; VN a sits in a component of more than two iff one of its CNs holds >= 3 lost
+// VNs, or its CNs name two different partners, or its single partner b has a CN with >= 3 lost VNs or a partner other
+// than a.  No union–find, so the 16-bit packed CN words serve here too (two workgroups per CU) — for position-structured
+// graphs only, i.e. the 2-byte adjacency; arbitrary graphs (tail-biting, uncoupled) keep the 32-bit words.
 #include "common.h"
 #include "kernel_util.h"
+#include "cn_words.h"
 
 namespace {
 
@@ -26,9 +30,8 @@ enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_NE = 9, S_LOST = 10, S_LOST_EXP = 11,
 
 struct Layout { int cn_state, U, fbits, frozen, q0, q1, pos_flag, scal, total, qcap, nw; };
 
-struct Args {
-    int dv, L, vns_pos, cns_pos, n, ncn, total_size, sweep_start, lost_lo, lost_hi;
-    uint32_t magic_v;
+struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
+    int dv, L, cns_pos, n, ncn, total_size, sweep_start, lost_lo, lost_hi;
     Layout lay;
     const void *vn_adj;
     const uint32_t *chan;
@@ -37,45 +40,11 @@ struct Args {
     uint32_t *ws;               // [T][ncn] CN words in global memory (ensembles beyond the LDS)
 };
 
-constexpr uint32_t kParentMask = 0x3FFFFFFFu;
-
-// G = true: the words live in a global-memory workspace; plain reads then go past the CU's L1 (agent-scope loads) so
-// that they see what the atomics did in L2.
-template <bool G>
-__device__ __forceinline__ uint32_t ldg(const uint32_t *p, uint32_t x)
-{
-    if constexpr (G) return __hip_atomic_load(&p[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else             return p[x];
-}
-
-template <bool G>
-__device__ __forceinline__ uint32_t uf_find(uint32_t *p, uint32_t x)
-{
-    for (;;) {
-        const uint32_t px = ldg<G>(p, x) & kParentMask;
-        if (px == x) return x;
-        const uint32_t gp = ldg<G>(p, px) & kParentMask;
-        if (gp != px) atomicCAS(&p[x], px, gp);        // path halving; only ever replaces a parent by an ancestor
-        x = px;
-    }
-}
-
-template <bool G>
-__device__ __forceinline__ void uf_unite(uint32_t *p, uint32_t a, uint32_t b)
-{
-    for (;;) {
-        a = uf_find<G>(p, a); b = uf_find<G>(p, b);
-        if (a == b) return;
-        if (a < b) { const uint32_t t = a; a = b; b = t; }          // hook the larger root under the smaller
-        if (atomicCAS(&p[a], a, b) == a) return;
-    }
-}
-
-template <int DV, bool A16, bool G>
-__global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
+template <int DV, bool A16, class ST>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void peel_sweep_kernel(const Args a)   // see full_bp.hip
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *cn_state = G ? a.ws + (size_t)blockIdx.x * a.ncn : lds + a.lay.cn_state;
+    uint32_t *cn_state = ST::kGlobal ? a.ws + (size_t)blockIdx.x * a.ncn : lds + a.lay.cn_state;
     uint32_t *U = lds + a.lay.U;
     uint32_t *fbits = lds + a.lay.fbits;
     uint32_t *frozen = lds + a.lay.frozen;
@@ -90,7 +59,8 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
     const uint32_t *ch = a.chan + (size_t)trial * nw;
     auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };
 
-    for (int c = tid; c < ncn; c += kBlock) cn_state[c] = 0;
+    for (int c = tid; c < ST::words(ncn); c += kBlock) cn_state[c] = 0;
+    auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = pos_of(j); v.t = j - v.pos * a.vns_pos; return v; };
     int ne_local = 0;
     for (int w = tid; w < nw; w += kBlock) {
         uint32_t x = ch[w];
@@ -120,8 +90,10 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = j0 + u * kBlock;
-            if (j < n && er[u])
-                for (int i = 0; i < dv; i++) atomicAdd(&cn_state[c[u][i]], kCntOne + (uint32_t)j);
+            if (j < n && er[u]) {
+                const Vn v = make_vn(j);
+                for (int i = 0; i < dv; i++) ST::add(cn_state, c[u][i], v, i, a.vns_pos, true, false);
+            }
         }
     }
     __syncthreads();
@@ -135,17 +107,19 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
         if (tid == 0) { scal[S_PUSH + gn] = 0; scal[S_OVF + gn] = 0; scal[S_REM + gn] = 0; }
         int removed = 0;
         auto release = [&](int c) {
-            const uint32_t w = ldg<G>(cn_state, (uint32_t)c);
-            if ((w >> kCntShift) != 1u) return;
-            const int j = (int)(w & kSumMask);
+            const int j = ST::lone_vn(cn_state, c, a);
+            if (j < 0) return;
+            const Vn v = make_vn(j);
             int32_t cc[8];
-            load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+            load_adj<DV, A16>(adj, dv, j, v.pos, a.cns_pos, cc);
             const uint32_t bit = 1u << (j & 31);
             if (!(atomicAnd(&U[j >> 5], ~bit) & bit)) return;
             removed++;
+            uint32_t o[8];
+            for (int i = 0; i < dv; i++) o[i] = ST::remove_cnt(cn_state, cc[i], v, i, a.vns_pos);
+            for (int i = 0; i < dv; i++) ST::remove_fold(cn_state, cc[i], v, i, a.vns_pos);
             for (int i = 0; i < dv; i++) {
-                const uint32_t o = atomicSub(&cn_state[cc[i]], kCntOne + (uint32_t)j) >> kCntShift;
-                if (o == 2u && cc[i] < cn_lim) {                    // transition to one VN: may fire (PD:305-308)
+                if (o[i] == 2u && cc[i] < cn_lim) {                 // transition to one VN: may fire (PD:305-308)
                     const int idx = atomicAdd(&scal[S_PUSH + g], 1);
                     if (idx < qcap) qn[idx] = (uint32_t)cc[i]; else scal[S_OVF + g] = 1;
                 }
@@ -157,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             // overflow) takes every other CN < total_size holding one VN: those got there by a transition.
             for (int base = 0; base < cn_lim; base += kBlock) {
                 const int c = base + tid;
-                const bool one = c < cn_lim && (ldg<G>(cn_state, (uint32_t)c) >> kCntShift) == 1u;
+                const bool one = c < cn_lim && ST::cnt(cn_state, c) == 1u;
                 bool v, fz;
                 if (iter == 0) { v = one && c >= a.sweep_start; fz = one && c < a.sweep_start; }
                 else           { fz = c < cn_lim && ((frozen[c >> 5] >> (c & 31)) & 1u); v = one && !fz; }
@@ -200,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
         }
         return in_range && all_inside;
     };
-    for (int c = tid; c < ncn; c += kBlock) cn_state[c] = (uint32_t)c;       // every CN its own root, size 0
+    for (int c = tid; c < ST::words(ncn); c += kBlock) cn_state[c] = 0;      // CN words over the lost VNs only, from here on
     __syncthreads();
     for (int w = tid; w < nw; w += kBlock) {
         uint32_t x = U[w], keep = 0;
@@ -210,38 +184,45 @@ __global__ __launch_bounds__(kBlock) void peel_sweep_kernel(const Args a)
             int32_t cc[8];
             if (is_lost(w * 32 + b, cc)) {
                 keep |= 1u << b;
-                for (int i = 1; i < dv; i++) uf_unite<G>(cn_state, (uint32_t)cc[0], (uint32_t)cc[i]);
+                const Vn v = make_vn(w * 32 + b);
+                for (int i = 0; i < dv; i++) ST::add(cn_state, cc[i], v, i, a.vns_pos, true, false);
             }
         }
         U[w] = keep;                                                // U := lost
     }
     __syncthreads();
-    for (int w = tid; w < nw; w += kBlock) {                       // component sizes, saturating at 3
-        uint32_t x = U[w];
-        while (x) {
-            const int b = __ffs((int)x) - 1;
-            x &= x - 1;
-            int32_t cc[8];
-            load_adj<DV, A16>(adj, dv, w * 32 + b, pos_of(w * 32 + b), a.cns_pos, cc);
-            const uint32_t r = uf_find<G>(cn_state, (uint32_t)cc[0]);
-            for (;;) {
-                const uint32_t old = ldg<G>(cn_state, r);
-                if ((old >> 30) == 3u || atomicCAS(&cn_state[r], old, old + (1u << 30)) == old) break;
+    // what VN v's CNs say: -2 = some CN holds >= 3 lost VNs or two different partners show up; -1 = no partner; else the partner
+    auto neighbourhood = [&](const Vn &v, const int32_t (&cc)[8]) {
+        int partner = -1;
+        for (int i = 0; i < dv; i++) {
+            const uint32_t k = ST::cnt(cn_state, cc[i]);
+            if (k >= 3u) return -2;
+            if (k == 2u) {
+                const int b = ST::partner(cn_state, cc[i], v, i, a);
+                if (partner >= 0 && b != partner) return -2;
+                partner = b;
             }
         }
-    }
-    __syncthreads();
+        return partner;
+    };
     int lost = 0, lost_exp = 0;
     for (int w = tid; w < nw; w += kBlock) {
         uint32_t x = U[w];
         while (x) {
             const int b = __ffs((int)x) - 1;
             x &= x - 1;
-            const int j = w * 32 + b;
-            int32_t cc[8];
-            load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+            const Vn va = make_vn(w * 32 + b);
+            int32_t cc[8], cb[8];
+            load_adj<DV, A16>(adj, dv, va.j, va.pos, a.cns_pos, cc);
             lost++;
-            if ((ldg<G>(cn_state, uf_find<G>(cn_state, (uint32_t)cc[0])) >> 30) == 3u) {      // component of > 2 VNs
+            int pa = neighbourhood(va, cc);
+            if (pa >= 0) {                                          // one partner: is {a, partner} closed?
+                const Vn vb = make_vn(pa);
+                load_adj<DV, A16>(adj, dv, vb.j, vb.pos, a.cns_pos, cb);
+                const int pb = neighbourhood(vb, cb);
+                if (pb != va.j) pa = -2;
+            }
+            if (pa == -2) {                                         // component of > 2 VNs
                 lost_exp++;
                 pos_flag[cc[0] / a.cns_pos] = 1;                    // int(u.birthday / cns_per_pos), PD:160,687
             }
@@ -283,27 +264,28 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
     int off = 0;
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
     a.lay.nw = (n + 31) / 32;
-    bool global_ws = false;
-    int qcap = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {                 // CN words in LDS if they fit, else in the workspace
+    // CN words: packed 16 bit (position-structured graphs only = the 2-byte adjacency), else 32 bit in LDS, else 32 bit in
+    // the workspace.  Two workgroups per CU (half the LDS each) when queues of >= 1024 entries still fit.
+    const bool can_pack = adj16 && (int64_t)p->dv * p->vns_pos <= 4096;
+    int mode = -1, qcap = 0;                                        // 0 packed, 1 wide, 2 wide in the workspace
+    for (int m = can_pack ? 0 : 1; m < 3 && mode < 0; m++) {
         off = 0;
-        a.lay.cn_state = take(global_ws ? 0 : ncn);
+        a.lay.cn_state = take(m == 0 ? Packed::lds_words(ncn) : m == 1 ? ncn : 0);
         a.lay.U = take(a.lay.nw);
         a.lay.fbits = take(((ncn + 63) / 64) * 2);
         a.lay.frozen = take(((ncn + 63) / 64) * 2);
         a.lay.pos_flag = take(p->L + p->dv);
         a.lay.scal = take(S_NSCAL);
-        // two workgroups per CU (half the LDS each) when queues of >= 1024 entries still fit, else the whole LDS
         int left = scldpc::kMaxLdsBytes / 4 - off;
         if (scldpc::kMaxLdsBytes / 8 - 256 - off >= 2 * 1024) left = scldpc::kMaxLdsBytes / 8 - 256 - off;
         qcap = (left / 2) & ~3;
         if (qcap > 8192) qcap = 8192;
-        if (qcap >= 256) break;
-        if (global_ws)
-            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
-                                     "scldpc_peel_sweep_device: %d VN bits + %d scan bits do not fit 160 KiB of LDS", n, ncn);
-        global_ws = true;
+        if (qcap >= 256) mode = m;
     }
+    if (mode < 0)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
+                                 "scldpc_peel_sweep_device: %d VN bits + %d scan bits do not fit 160 KiB of LDS", n, ncn);
+    const bool global_ws = mode == 2;
     a.lay.qcap = qcap; a.lay.q0 = take(qcap); a.lay.q1 = take(qcap); a.lay.total = off;
     if (global_ws) {
         void *ws = nullptr;
@@ -312,18 +294,14 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
     }
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.ncn = ncn;
     a.total_size = total_size; a.sweep_start = sweep_start; a.lost_lo = lost_lo; a.lost_hi = lost_hi;
-    a.magic_v = (uint32_t)((1ull << 32) / (uint32_t)p->vns_pos) + 1u;
-    for (int64_t q = 0; q <= p->L; q++) {                           // exactness of the reciprocal on [0, n)
-        const uint64_t x0 = (uint64_t)q * p->vns_pos, x1 = x0 ? x0 - 1 : 0;
-        if (((x0 * a.magic_v) >> 32) != (uint64_t)q || ((x1 * a.magic_v) >> 32) != x1 / (uint64_t)p->vns_pos)
-            return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: reciprocal division inexact");
-    }
+    if (!scldpc::magic_of(p->vns_pos, n > 4096 ? n : 4096, &a.magic_v) || !scldpc::magic_of(p->cns_pos, ncn, &a.magic_c))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: reciprocal division inexact");
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.out = d_out; a.lost_out = d_lost_bits;
     void (*kern)(const Args) = nullptr;
-    if (global_ws) kern = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true, true> : peel_sweep_kernel<4, false, true>)
-                                     : (adj16 ? peel_sweep_kernel<0, true, true> : peel_sweep_kernel<0, false, true>);
-    else           kern = p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true, false> : peel_sweep_kernel<4, false, false>)
-                                     : (adj16 ? peel_sweep_kernel<0, true, false> : peel_sweep_kernel<0, false, false>);
+#define PICK(ST) (p->dv == 4 ? (adj16 ? peel_sweep_kernel<4, true, ST> : peel_sweep_kernel<4, false, ST>) \
+                             : (adj16 ? peel_sweep_kernel<0, true, ST> : peel_sweep_kernel<0, false, ST>))
+    kern = mode == 0 ? PICK(Packed) : mode == 1 ? PICK(Wide) : PICK(WideG);
+#undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

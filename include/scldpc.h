@@ -131,7 +131,10 @@ int scldpc_sample_philox_ensemble_device(const scldpc_code_params *p, int32_t en
 /* decodeBP — flooding BP over the BEC to the fixpoint or max_it iterations, plus the size-2
  * stopping-set expurgation (BPF:900-1140).  max_it <= 0 ⇒ unlimited (BPT:825 `while(1)`).
  * is_term = 0 ⇒ truncated chain: CNs at positions >= L never send information (BPT:922-925,944-948).
- * d_rows / d_erased_bits may be NULL.  One workgroup decodes one trial. */
+ * d_rows / d_erased_bits may be NULL.  One workgroup decodes one trial.
+ * Precondition of all BP decoders (full, window, streaming): the graph has generate_code's position structure — edge i of
+ * VN j lies in CN position j / vns_pos + i (BPF:1712) — which is what every sampler of this library and of the reference's
+ * C simulators produces.  (The peeling entry points take arbitrary VN→CN tables in their int32 form.) */
 int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
                           const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                           int32_t max_it, int32_t is_term,
