@@ -120,7 +120,7 @@ def _oracle_counters(oracle, po, adj, chbits, decoder, **kw):
     return res, erased, None
 
 
-@pytest.mark.parametrize("L,N", [(50, 1000), (16, 200), (9, 24)])
+@pytest.mark.parametrize("L,N", [(50, 1000), (16, 200), (9, 24), (14, 1200)])    # N = 1200: 32-bit CN words in LDS
 @pytest.mark.parametrize("eps", [0.05, 0.3, 0.44, 0.48, 0.52, 0.95])
 def test_full_bp_equals_oracle_on_philox_inputs(E, oracle, L, N, eps):
     """Random seeds beyond the fixtures, incl. ε far from threshold: tiny ε floods the frontier queue
@@ -149,7 +149,7 @@ def test_full_bp_equals_oracle_on_philox_inputs(E, oracle, L, N, eps):
                 and (got[:, 2] == orows["first_pos"]).all(), (L, N, eps, is_term, max_it, t)
 
 
-@pytest.mark.parametrize("L,N,W,max_it,init_it", [(50, 1000, 20, 6, 60), (50, 1000, 10, 20, 0), (16, 200, 5, 3, 9),
+@pytest.mark.parametrize("L,N,W,max_it,init_it", [(50, 1000, 20, 6, 60), (50, 1000, 10, 20, 0), (16, 200, 5, 3, 9), (14, 1200, 5, 4, 10),
                                                   (16, 200, 30, 50, 0), (9, 24, 1, 1, 1), (9, 24, 4, 2, 0)])
 @pytest.mark.parametrize("eps", [0.1, 0.42, 0.47, 0.6])
 def test_sw_bp_equals_oracle_on_philox_inputs(E, oracle, L, N, W, max_it, init_it, eps):
@@ -340,7 +340,7 @@ def test_classical_window_matches_reference_golden(E, name):
         assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
 
 
-@pytest.mark.parametrize("L,N,W,max_it,eps", [(50, 1000, 20, 6, 0.465), (16, 200, 5, 3, 0.45), (9, 24, 2, 1, 0.5),
+@pytest.mark.parametrize("L,N,W,max_it,eps", [(50, 1000, 20, 6, 0.465), (16, 200, 5, 3, 0.45), (9, 24, 2, 1, 0.5), (14, 1200, 5, 4, 0.47),
                                               (16, 200, 30, 50, 0.47), (100, 2000, 10, 20, 0.47)])
 def test_classical_window_equals_oracle(E, oracle, L, N, W, max_it, eps):
     import torch
