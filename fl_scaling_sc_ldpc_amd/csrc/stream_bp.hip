@@ -26,7 +26,8 @@ namespace {
 
 using namespace scldpc_dev;
 
-constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kQCap = 8192, kMaxL = 256;
+constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kMaxL = 256;
+constexpr int kQCapTwo = 2048, kQCapOne = 8192;     // frontier-queue entries with two / one workgroup(s) per CU
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_NSCAL = 16 };
 
@@ -68,8 +69,11 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
     return false;
 }
 
-template <int ROWS>
-__global__ __launch_bounds__(kThreads) void stream_bp_kernel(const Args a)
+// ROWS <= 4 (at most 4096 counter words, N <= 1024 at (4,8)): the LDS part is 34 KB, so two workgroups fit a CU if the
+// compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip) — the kernel waits on L2 round trips most of the time and a second
+// stream on the CU hides them.  Larger ensembles need the whole LDS for the counters and keep the registers they want.
+template <int ROWS, int kQCap>
+__device__ __forceinline__ void stream_bp_body(const Args &a)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                   // nb bucket counters (ranking)
@@ -347,6 +351,19 @@ __global__ __launch_bounds__(kThreads) void stream_bp_kernel(const Args a)
     }
 }
 
+template <int ROWS>
+__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_bp_kernel_two_per_cu(const Args a)
+{
+    stream_bp_body<ROWS, kQCapTwo>(a);
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(kThreads) void stream_bp_kernel(const Args a)
+{
+    stream_bp_body<ROWS, kQCapOne>(a);
+}
+
+
 int make_state_layout(const scldpc_code_params *p, StateLayout *lay)
 {
     const size_t L = p->L, V = p->vns_pos, C = p->cns_pos, S = (size_t)p->cns_pos * p->dc, dv = p->dv;
@@ -424,10 +441,10 @@ extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nst
     }
     make_state_layout(p, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
-    const size_t lds_bytes = 4u * ((size_t)a.nb + 2 * kQCap + 32 + kWaves * kWaves + kMaxL + S_NSCAL);
     const int rows = a.nb / kThreads;
-    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel<1> : rows == 2 ? stream_bp_kernel<2>
-                               : rows == 4 ? stream_bp_kernel<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
+    const size_t lds_bytes = 4u * ((size_t)a.nb + 2 * (rows <= 4 ? kQCapTwo : kQCapOne) + 32 + kWaves * kWaves + kMaxL + S_NSCAL);
+    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel_two_per_cu<1> : rows == 2 ? stream_bp_kernel_two_per_cu<2>
+                               : rows == 4 ? stream_bp_kernel_two_per_cu<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
