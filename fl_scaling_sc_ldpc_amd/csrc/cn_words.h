@@ -23,6 +23,7 @@ struct Vn { int j, pos, t; };
 template <bool G>
 struct WideT {
     static constexpr bool kGlobal = G;
+    static constexpr bool kHasDeg = true;          // the CN degree rides in the word (trajectory mode)
     static __host__ __device__ int lds_words(int nk) { return G ? 0 : nk; }
     static __host__ __device__ int words(int nk) { return nk; }
     static __device__ __forceinline__ uint32_t ld(const uint32_t *st, int c)
@@ -59,6 +60,7 @@ using WideG = WideT<true>;
 
 struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of word c >> 1
     static constexpr bool kGlobal = false;
+    static constexpr bool kHasDeg = false;         // trajectory mode keeps the few degrees it needs in a side array
     static __host__ __device__ int lds_words(int nk) { return (nk + 1) / 2; }
     static __host__ __device__ int words(int nk) { return (nk + 1) / 2; }
     static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int i, int V, bool erased, bool)

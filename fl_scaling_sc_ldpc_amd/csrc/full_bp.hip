@@ -89,6 +89,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
     ne_local = wave_sum(ne_local);
     if (lane == 0 && ne_local) atomicAdd(&scal[S_NE], ne_local);
 
+    // Trajectory rows with packed words: deg_1_iter's iteration-0 quirk (BPF:969-978) asks for CNs of degree 1 whose only VN
+    // is known.  Only the first and last dv-1 CN positions of the chain can have a degree below dc, so their degrees are
+    // counted into a byte array that borrows queue 1 (first written by iteration 0's releases, after the scan has used it).
+    constexpr bool kSideDeg = TRAJ && !ST::kHasDeg;
+    uint32_t *degb = q[1];
+    const int ms = dv - 1, tail0 = a.L * a.cns_pos;
+    auto boundary = [&](int c) {                    // index into degb, or -1 for a CN of the chain's interior
+        return c < ms * a.cns_pos ? c : c >= tail0 ? ms * a.cns_pos + (c - tail0) : -1;
+    };
+    if constexpr (kSideDeg) {
+        for (int w = tid; w < (2 * ms * a.cns_pos + 3) / 4; w += BLOCK) degb[w] = 0;
+        __syncthreads();
+    }
+
     // ---- build: every erased VN adds itself to its dv CNs (TRAJ: every VN also adds to deg) ----
     // Loads are unconditional so that each wave instruction reads 1 KiB contiguous (dv = 4).
     for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {
@@ -108,7 +122,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
             const int j = j0 + u * BLOCK;
             if (j < n && (TRAJ || er[u])) {
                 const Vn v = make_vn(j);
-                for (int i = 0; i < dv; i++) ST::add(cn_state, c[u][i], v, i, V, er[u], TRAJ);
+                for (int i = 0; i < dv; i++) {
+                    ST::add(cn_state, c[u][i], v, i, V, er[u], TRAJ);
+                    if constexpr (kSideDeg) {
+                        const int b = boundary(c[u][i]);
+                        if (b >= 0) atomicAdd(&degb[b >> 2], 1u << ((b & 3) * 8));
+                    }
+                }
             }
         }
     }
@@ -164,8 +184,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
                 if (c < cn_lim) {
                     const uint32_t k = ST::cnt(cn_state, c);
                     v = k == 1u;
-                    if (TRAJ && iter == 0)                          // degree-1 CN whose only VN is known (BPF:973)
-                        extra += (k == 0u && ST::deg(cn_state, c) == 1u);
+                    if (TRAJ && iter == 0) {                        // degree-1 CN whose only VN is known (BPF:973)
+                        uint32_t d;
+                        if constexpr (kSideDeg) { const int b = boundary(c); d = b < 0 ? 0xFFu : (degb[b >> 2] >> ((b & 3) * 8)) & 0xFFu; }
+                        else                    d = ST::deg(cn_state, c);
+                        extra += (k == 0u && d == 1u);
+                    }
                 }
                 const unsigned long long m = __ballot(v);
                 if (c - lane < cn_lim) {                            // this wave's 64-CN slice starts inside the range
@@ -350,8 +374,10 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
                                  p->dc, p->dv, n);
     const bool traj = d_rows != nullptr;
     Args a{};
-    // two workgroups per CU with the packed CN words when the ensemble allows it (and no trajectory rows)
-    const bool packed = !traj && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
+    // two workgroups per CU with the packed CN words when the ensemble allows it
+    // (trajectory rows: the side array of boundary degrees must fit queue 1)
+    const bool packed = packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0 &&
+                        (!traj || 2 * (p->dv - 1) * p->cns_pos <= 4 * a.lay.qcap);
     bool global_ws = false;
     // Wide words: two workgroups per CU when everything (with queues of >= 1024 entries) fits half the LDS, else one
     auto fits = [&](auto tag, Layout *lay) {
@@ -382,7 +408,7 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     const bool d4 = p->dv == 4;
 #define PICK(ST, TRAJ, BLK) (d4 ? (adj16 ? full_bp_kernel<ST, TRAJ, 4, true, BLK> : full_bp_kernel<ST, TRAJ, 4, false, BLK>) \
                                 : (adj16 ? full_bp_kernel<ST, TRAJ, 0, true, BLK> : full_bp_kernel<ST, TRAJ, 0, false, BLK>))
-    if (packed) kern = PICK(Packed, false, 1024);
+    if (packed) kern = traj ? PICK(Packed, true, 1024) : PICK(Packed, false, 1024);
     else if (global_ws) kern = traj ? PICK(WideG, true, 1024) : PICK(WideG, false, 1024);
     else if (traj) kern = PICK(Wide, true, 1024);
     else kern = PICK(Wide, false, 1024);
