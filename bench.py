@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16384, help="trials per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flooding", action="store_true",
+                    help="decode with the level-synchronous kernel (one barrier round per flooding iteration, reports the "
+                         "iteration count) instead of the fixpoint kernel (same outputs, no iteration count)")
     ap.add_argument("--overlap", action="store_true",
                     help="two streams: the sampler of step k+1 beside the decoder of step k (default: one stream)")
     ap.add_argument("--no-overlap", action="store_true", help="(default) one stream: sample, then decode, then accumulate")
@@ -149,7 +152,10 @@ def main():
             s_dec.wait_event(sampled[b])
             if e:
                 e[2].record(s_dec)
-            E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
+            if a.flooding:
+                E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
+            else:
+                E.full_bp_fixpoint(p, d_adj[b], d_ch[b], counters=d_cnt[b])
             if e:
                 e[3].record(s_dec)
             E.accumulate_run(d_cnt[b], run, 0)
@@ -194,17 +200,20 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload_name(), "trials_per_gpu_per_step": B,
                        "step": "device sample (code+channel) -> decodeBP -> plr_computation",
+                       "decoder": ("flooding, one barrier round per iteration" if a.flooding else
+                                   "fixpoint of unlimited flooding by chain-following peeling (every output of decodeBP "
+                                   "except the iteration count; equality with the flooding kernel is a test)"),
                        "rng": "philox4x32-10 keyed by (seed, trial)",
                        "adjacency": "int32 global ids" if a.adj32 else "uint16 position-local ids", "parallelism": f"trial-sharded x{world}",
                        "streams": "sampler(k+1) || decoder(k), double-buffered" if nbuf == 2 else "single stream"},
-            "roofline": {"bound": "hbm", "kernel": "full_bp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "full_bp_kernel" if a.flooding else "full_bp_fixpoint_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_trial": b_alg, "trials_per_launch": B, "ms_per_launch": ms_bp},
             "kernels_ms": {"sample_philox": ms_sample, "full_bp": ms_bp},
             "decode_only_trials_per_s_per_gpu": B / (ms_bp * 1e-3),
             "results": {"FER": r["frame_err"] / r["frames"], "BLER": r["block_err"] / p.L / r["frames"],
                         "BER": r["users_err"] / p.n / r["frames"], "FER_exp": r["frame_err_exp"] / r["frames"],
-                        "mean_iterations": r["iterations"] / r["frames"]},
+                        ("mean_iterations" if a.flooding else "mean_barrier_rounds"): r["iterations"] / r["frames"]},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -31,6 +31,7 @@ EXPORTS = (
     "scldpc_peel_pick_device", "scldpc_peel_pick_device_adj16", "scldpc_r1_moments_device",
     "scldpc_stream_state_bytes", "scldpc_stream_run_device",
     "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16", "scldpc_sample_philox_ensemble_device",
+    "scldpc_full_bp_fixpoint_device", "scldpc_full_bp_fixpoint_device_adj16",
 )
 
 
@@ -88,6 +89,8 @@ def lib():
     L.scldpc_sample_glibc_next_host.argtypes = [pp, vp, dbl, i32, vp, i32, vp, vp]
     L.scldpc_sample_philox_device.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
     L.scldpc_sample_philox_ensemble_device.argtypes = [pp, i32, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
+    L.scldpc_full_bp_fixpoint_device.argtypes = [pp, i32, vp, vp, i32, vp, vp, vp]
+    L.scldpc_full_bp_fixpoint_device_adj16.argtypes = L.scldpc_full_bp_fixpoint_device.argtypes
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes

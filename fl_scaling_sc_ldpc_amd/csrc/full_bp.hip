@@ -314,6 +314,249 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
     }
 }
 
+// =================================================================================================
+// Fixpoint variant: the residual of UNLIMITED flooding without walking its iterations one barrier at a time.
+//
+// On the BEC the set flooding BP converges to is the closure of "a CN with exactly one erased neighbour resolves it" and
+// does not depend on the order in which CNs fire — only the iteration COUNT does.  When nobody asks
+// for the count (no iteration cap, no trajectory rows) a lane that has released a VN may therefore go straight on with a
+// CN that this very release left with one erased neighbour, instead of queueing it for the next barrier round: the
+// ~230 dependent levels of a trial at eps = 0.48 become ~230 steps of (one row gather + two rounds of LDS atomics) in a
+// row, with a barrier only when chains end and work is redistributed.  Everything reported except
+// SCLDPC_C_ITERATIONS (here: the number of barrier rounds) is identical to full_bp_kernel's — tests compare them.
+//
+// Without a barrier between a CN's updates and its next read the two-atomic packed word needs an order and a check:
+//   * a release XORs its id out of the fold FIRST and decrements the count SECOND; every release claims its VN in U before
+//     either.  The thread whose decrement returns count 2 owns the CN's follow-up; of the two neighbours not yet
+//     decremented one is its own VN, so the fold it gets back is the other one's id X if X is unclaimed, and X or 0 if X
+//     is being released elsewhere;
+//   * the follow-up is taken only if the decoded VN really has this CN on the decoded edge AND its claim in U succeeds.
+//     An unclaimed erased neighbour of the CN can only be X itself, so nothing is ever released wrongly, and if the claim
+//     fails X is on its way out anyway.
+// =================================================================================================
+template <bool A16, int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void full_bp_fixpoint_kernel(const Args a)
+{
+    using ST = Packed;
+    constexpr int DV = 4;
+    extern __shared__ uint32_t lds[];
+    const int trial = blockIdx.x;
+    uint32_t *cn_state = lds + a.lay.cn_state;
+    uint32_t *U = lds + a.lay.U;
+    uint32_t *fbits = lds + a.lay.fbits;
+    uint32_t *q[2] = {lds + a.lay.q0, lds + a.lay.q1};
+    int *pos_cnt = reinterpret_cast<int *>(lds + a.lay.pos_cnt);
+    int *pos_ss = reinterpret_cast<int *>(lds + a.lay.pos_ss);
+    int *scal = reinterpret_cast<int *>(lds + a.lay.scal);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = a.n, nk = a.nk, cn_lim = a.cn_lim, nw = a.lay.nw, qcap = a.lay.qcap;
+    const int V = a.vns_pos, C = a.cns_pos, L = a.L;
+    const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * DV * (A16 ? 2 : 4);
+    const uint32_t *ch = a.chan + (size_t)trial * nw;
+    auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
+
+    for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
+    int ne_local = 0;
+    for (int w = tid; w < nw; w += BLOCK) {
+        uint32_t x = ch[w];
+        if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+        U[w] = x;
+        ne_local += __popc(x);
+    }
+    if (tid < S_NSCAL) scal[tid] = 0;
+    for (int i = tid; i < L; i += BLOCK) { pos_cnt[i] = 0; pos_ss[i] = 0; }
+    __syncthreads();
+    ne_local = wave_sum(ne_local);
+    if (lane == 0 && ne_local) atomicAdd(&scal[S_NE], ne_local);
+    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {                  // build, as in full_bp_kernel
+        int32_t c[4][8];
+        bool er[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * BLOCK;
+            er[u] = false;
+            if (j < n) {
+                load_adj<DV, A16>(adj, DV, j, (int)__umulhi((uint32_t)j, a.magic_v), C, c[u]);
+                er[u] = (U[j >> 5] >> (j & 31)) & 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * BLOCK;
+            if (j < n && er[u]) {
+                const Vn v = make_vn(j);
+#pragma unroll
+                for (int i = 0; i < DV; i++) ST::add(cn_state, c[u][i], v, i, V, true, false);
+            }
+        }
+    }
+    __syncthreads();
+    const int nch = scal[S_NE];
+
+    int removed = 0, rounds = 0, ncur = 0;
+    bool overflow = false;
+    // One release step.  `e` = [half-word : 16 | CN : 16]: CN c believed to have exactly one erased neighbour, and the
+    // packed half-word saying so (cnt 1, fold).  Releases that neighbour if it checks out and returns in out[0..3] the
+    // entries of the CNs this release left with one erased neighbour (0 = none).
+    auto step = [&](uint32_t e, uint32_t (&out)[DV]) {
+#pragma unroll
+        for (int i = 0; i < DV; i++) out[i] = 0;
+        const int c = (int)(e & 0xFFFFu);
+        const uint32_t h = e >> 16;
+        if ((h >> 12) != 1u) return;
+        const uint32_t lid = h & 0xFFFu;
+        const int i1 = (int)__umulhi(lid, a.magic_v);                       // edge index lid / V
+        const int pos_c = (int)__umulhi((uint32_t)c, a.magic_c);
+        const int pos = pos_c - i1, t = (int)lid - i1 * V;
+        if (i1 >= DV || pos < 0 || pos >= L) return;                        // a fold caught between two updates
+        const int j = pos * V + t;
+        int32_t cc[8];
+        load_adj<DV, A16>(adj, DV, j, pos, C, cc);
+        if (cc[i1] != c) return;                                            // not this CN's neighbour: same reason
+        const uint32_t bit = 1u << (j & 31);
+        if (!(atomicAnd(&U[j >> 5], ~bit) & bit)) return;                   // already released, or being released elsewhere
+        removed++;
+#pragma unroll
+        for (int i = 0; i < DV; i++) atomicXor(&cn_state[cc[i] >> 1], (uint32_t)(i * V + t) << ((cc[i] & 1) * 16));
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            const int sh = (cc[i] & 1) * 16;
+            const uint32_t w = (atomicSub(&cn_state[cc[i] >> 1], 0x1000u << sh) >> sh) & 0xFFFFu;
+            if ((w >> 12) == 2u && cc[i] < cn_lim) {
+                out[i] = ((0x1000u | (w & 0xFFFu)) << 16) | (uint32_t)cc[i];
+            }
+        }
+    };
+    auto entry_of = [&](int c) { return (ST::half(cn_state, c) << 16) | (uint32_t)c; };
+
+    // ---- phase A: barrier rounds over the shared queue while the frontier is wide --------------------------------
+    // ---- phase B: once it is narrow every wave keeps the entries it gets and the ones its own releases create in a
+    //      private queue and runs them level by level on its own: no workgroup barrier, no shared counter -------------
+    // every wave takes part (measured: 16 waves with a few entries each beat 4 waves with many — the waves' dependent
+    // steps overlap); the shared queue is dealt out round-robin
+    constexpr int kWaves = BLOCK / 64, kSwitch = 16 * kWaves;
+    const int wave = tid >> 6;
+    const int wcap = (qcap / kWaves) & ~1;          // private queue space per wave: two halves of wcap/2 entries
+    bool scan = true;
+    for (;;) {
+        const int g = rounds % 3, gn = (rounds + 1) % 3;
+        uint32_t *qc = q[rounds & 1], *qn = q[(rounds + 1) & 1];
+        if (tid == 0) { scal[S_PUSH + gn] = 0; scal[S_OVF + gn] = 0; }
+        auto push_shared = [&](const uint32_t (&out)[DV]) {
+#pragma unroll
+            for (int i = 0; i < DV; i++) {
+                if (out[i]) {
+                    const int idx = atomicAdd(&scal[S_PUSH + g], 1);
+                    if (idx < qcap) qn[idx] = out[i]; else overflow = true;
+                }
+            }
+        };
+        if (scan) {
+            // every CN < cn_lim that shows one erased neighbour right now (a stale entry dies in step())
+            for (int base = 0; base < cn_lim; base += BLOCK) {
+                const int c = base + tid;
+                const bool v = c < cn_lim && ST::cnt(cn_state, c) == 1u;
+                const unsigned long long m = __ballot(v);
+                if (c - lane < cn_lim) {
+                    if (lane == 0) fbits[c >> 5] = (uint32_t)m;
+                    if (lane == 32) fbits[c >> 5] = (uint32_t)(m >> 32);
+                }
+            }
+            __syncthreads();
+            for (int base = 0; base < cn_lim; base += BLOCK) {
+                const int c = base + tid;
+                if (c < cn_lim && ((fbits[c >> 5] >> (c & 31)) & 1u)) { uint32_t out[DV]; step(entry_of(c), out); push_shared(out); }
+            }
+        } else if (ncur > kSwitch || wcap < 128) {
+            for (int k = tid; k < ncur; k += BLOCK) { uint32_t out[DV]; step(qc[k], out); push_shared(out); }
+        } else {
+            // phase B.  Wave w takes entries w, w+16, ... of the shared queue into its private queue (in qn, which nobody
+            // else touches now), then runs to exhaustion.
+            uint32_t *mine = qn + wave * wcap;
+            const int half_cap = wcap / 2;
+            int cnt = (ncur - wave + kWaves - 1) / kWaves, cur = 0;         // entries wave, wave + kWaves, ...
+            if (cnt < 0) cnt = 0;
+            if (lane < cnt) mine[lane] = qc[wave + lane * kWaves];
+            while (cnt > 0) {
+                uint32_t *src = mine + cur * half_cap, *dst = mine + (cur ^ 1) * half_cap;
+                int ncnt = 0;
+                for (int base = 0; base < cnt; base += 64) {
+                    uint32_t out[DV];
+#pragma unroll
+                    for (int i = 0; i < DV; i++) out[i] = 0;
+                    if (base + lane < cnt) step(src[base + lane], out);
+#pragma unroll
+                    for (int i = 0; i < DV; i++) {                          // append: wave-synchronous, no atomics
+                        const unsigned long long m = __ballot(out[i] != 0u);
+                        if (out[i]) {
+                            const int idx = ncnt + __popcll(m & ((1ull << lane) - 1ull));
+                            if (idx < half_cap) dst[idx] = out[i]; else overflow = true;
+                        }
+                        ncnt += __popcll(m);
+                    }
+                }
+                cnt = min(ncnt, half_cap);
+                cur ^= 1;
+            }
+        }
+        if (overflow) scal[S_OVF + g] = 1;
+        __syncthreads();
+        rounds++;
+        overflow = false;
+        scan = scal[S_OVF + g] != 0;            // an overflowing queue dropped CNs: find them by a scan
+        ncur = scan ? 0 : scal[S_PUSH + g];
+        if (!scan && ncur == 0) break;
+    }
+    removed = wave_sum(removed);
+    if (lane == 0 && removed) atomicAdd(&scal[S_REM], removed);
+    __syncthreads();
+    const int ne = nch - scal[S_REM];
+
+    // ---- per-position erasure counts + size-2 stopping sets (BPF:1067-1133), as in full_bp_kernel ----
+    if (ne > 0) {
+        for (int w = tid; w < nw; w += BLOCK) {
+            uint32_t x = U[w];
+            while (x) {
+                const int b = __ffs((int)x) - 1;
+                x &= x - 1;
+                const Vn v = make_vn(w * 32 + b);
+                atomicAdd(&pos_cnt[v.pos], 1);
+                int32_t cc[8];
+                load_adj<DV, A16>(adj, DV, v.j, v.pos, C, cc);
+                bool pair = true;
+                int partner = -1;
+                for (int i = 0; i < DV; i++) {
+                    const int b2 = ST::partner(cn_state, cc[i], v, i, a);
+                    if (b2 < 0 || (i > 0 && b2 != partner)) { pair = false; break; }
+                    partner = b2;
+                }
+                if (pair && (int)__umulhi((uint32_t)partner, a.magic_v) == v.pos) atomicAdd(&pos_ss[v.pos], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (a.erased_out)
+        for (int w = tid; w < nw; w += BLOCK) a.erased_out[(size_t)trial * nw + w] = U[w];
+    if (tid == 0) {
+        int be = 0, ee = 0, bee = 0;
+        for (int pos = 0; pos < L; pos++) {
+            if (pos_cnt[pos] > 0) be++;
+            const int e = pos_cnt[pos] - pos_ss[pos];
+            if (e > 0 && bee == 0) { ee = e; bee = 1; }             // only the FIRST such position (BPF:1126-1132)
+        }
+        int32_t *o = a.counters + (size_t)trial * SCLDPC_NCOUNTERS;
+        o[SCLDPC_C_NUM_ERASURES] = ne;
+        o[SCLDPC_C_NUM_BLOCKS_ERR] = be;
+        o[SCLDPC_C_NUM_ERASURES_EXP] = ee;
+        o[SCLDPC_C_NUM_BLOCKS_ERR_EXP] = bee;
+        o[SCLDPC_C_NUM_ERASURES_P1] = 0;
+        o[SCLDPC_C_ITERATIONS] = rounds;                            // barrier rounds, NOT flooding iterations
+        o[SCLDPC_C_STATUS] = 0;
+        o[SCLDPC_C_CHANNEL_ERASURES] = nch;
+    }
+}
+
 // LDS carve.  `budget` = bytes this workgroup may take (160 KiB alone on the CU, 80 KiB when two share it).
 template <class ST>
 int make_layout(const scldpc_code_params *p, int budget_bytes, Layout *lay)
@@ -439,4 +682,47 @@ extern "C" int scldpc_full_bp_device_adj16(const scldpc_code_params *p, int32_t 
 {
     return launch_full_bp(p, ntrials, d_vn_adj16, true, d_chan_bits, max_it, is_term, d_counters, d_rows, rows_cap,
                           d_erased_bits, stream);
+}
+
+// The fixpoint of unlimited flooding by chain-following peeling (full_bp_fixpoint_kernel).  Ensembles the packed words do
+// not cover (dv != 4, dv*vns_pos > 4096, LDS) take the level-synchronous kernel: same results, ITERATIONS = flooding iterations.
+static int launch_full_bp_fixpoint(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
+                                   const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
+                                   uint32_t *d_erased_bits, void *stream)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    Args a{};
+    const bool ok = p->dv == 4 && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
+    if (!ok)
+        return launch_full_bp(p, ntrials, d_vn_adj, adj16, d_chan_bits, 0, is_term, d_counters, nullptr, 0, d_erased_bits, stream);
+    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_fixpoint_device: null buffer or negative ntrials");
+    if (ntrials == 0) return SCLDPC_OK;
+    const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
+    a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
+    a.cn_lim = is_term ? nk : p->L * p->cns_pos;                    // BPT:944-948
+    if (!scldpc::magic_of(p->vns_pos, n > 4096 ? n : 4096, &a.magic_v) || !scldpc::magic_of(p->cns_pos, nk, &a.magic_c))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_full_bp_fixpoint_device: reciprocal division inexact for this size");
+    a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
+    void (*kern)(const Args) = adj16 ? full_bp_fixpoint_kernel<true, 1024> : full_bp_fixpoint_kernel<false, 1024>;
+    const size_t lds_bytes = 4u * (size_t)a.lay.total;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(1024), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}
+
+extern "C" int scldpc_full_bp_fixpoint_device(const scldpc_code_params *p, int32_t ntrials,
+                                              const int32_t *d_vn_adj, const uint32_t *d_chan_bits, int32_t is_term,
+                                              int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj, false, d_chan_bits, is_term, d_counters, d_erased_bits, stream);
+}
+
+extern "C" int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                                    const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits, int32_t is_term,
+                                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj16, true, d_chan_bits, is_term, d_counters, d_erased_bits, stream);
 }

@@ -162,6 +162,24 @@ def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=Fa
     return {"counters": counters, "rows": rows, "erased": erased}
 
 
+def full_bp_fixpoint(p, d_adj, d_chan, is_term=True, want_erased=False, counters=None):
+    """What unlimited decodeBP converges to, without its iteration count (scldpc_full_bp_fixpoint_device): counters as
+    full_bp's except column 5 (barrier rounds of the kernel) — for runs with no iteration cap and no trajectory rows."""
+    _require_gpu()
+    T = d_adj.shape[0]
+    assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    assert tuple(d_adj.shape[1:]) == (p.n, p.dv) and tuple(d_chan.shape) == (T, p.nw)
+    dev = d_adj.device
+    if counters is None:
+        counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+    erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    fn = lib().scldpc_full_bp_fixpoint_device_adj16 if _is_adj16(d_adj) else lib().scldpc_full_bp_fixpoint_device
+    check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), 1 if is_term else 0, counters.data_ptr(),
+             erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    return {"counters": counters, "rows": None, "erased": erased}
+
+
 def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None, classical=False):
     """decodeBP_SW for a batch resident on the device: square window (BPW:628-912) or, with classical=True, the
     classical window kept in BPF:627-897 (init_it unused)."""

@@ -141,6 +141,18 @@ int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
                           int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
                           uint32_t *d_erased_bits, void *stream);
 
+/* decodeBP with no iteration cap, when only what it converges to is wanted (the reference's bp_lim_iter with MAX_IT beyond
+ * reach, BPF:2080-2083, prints nothing that depends on the iteration count): same counters as scldpc_full_bp_device with
+ * max_it = 0 EXCEPT SCLDPC_C_ITERATIONS, which here counts the kernel's barrier rounds, and STATUS, which is always 0.
+ * On the BEC the fixpoint does not depend on the order in which CNs resolve VNs, so a thread follows the chain its own
+ * release opens instead of waiting for the next flooding iteration (full_bp.hip). */
+int scldpc_full_bp_fixpoint_device(const scldpc_code_params *p, int32_t ntrials,
+                                   const int32_t *d_vn_adj, const uint32_t *d_chan_bits, int32_t is_term,
+                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t ntrials,
+                                         const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits, int32_t is_term,
+                                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+
 /* decodeBP_SW, square window (BPW:628-912): window of W positions, init_it iterations for the
  * first window and max_it for the others (init_it == 0 ⇒ max_it, BPW:2101-2102). */
 int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,

@@ -359,3 +359,42 @@ def test_classical_window_equals_oracle(E, oracle, L, N, W, max_it, eps):
         assert c[t, :5].tolist() == [res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"],
                                      res["num_blocks_err_exp"], res["num_erasures_p1"]], (L, N, W, t)
         assert c[t, 5] == res["iterations"] and (er[t] == erased).all()
+
+
+@pytest.mark.parametrize("L,N", [(50, 1000), (16, 200), (9, 24), (60, 1024), (14, 1200)])
+@pytest.mark.parametrize("eps", [0.02, 0.3, 0.44, 0.47, 0.48, 0.49, 0.52, 0.7, 0.95])
+@pytest.mark.parametrize("is_term", [True, False])
+def test_fixpoint_kernel_equals_flooding_kernel(E, L, N, eps, is_term):
+    """Chain-following peeling (scldpc_full_bp_fixpoint_device) against the level-synchronous kernel: every counter
+    except the iteration count, and the residual erasure pattern, trial by trial; both adjacency formats."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 48 if N >= 1000 else 96
+    d_adj, d_ch = E.sample_philox(p, 5, int(eps * 100) * 1000 + L, T, eps, adj16=True)
+    ref = E.full_bp(p, d_adj, d_ch, is_term=is_term, want_erased=True)
+    adj32 = torch.from_numpy(E.adj16_to_global(p, d_adj.cpu().numpy())).to(d_adj.device)
+    for adj in (d_adj, adj32):
+        out = E.full_bp_fixpoint(p, adj, d_ch, is_term=is_term, want_erased=True)
+        torch.cuda.synchronize()
+        c, r = out["counters"].cpu().numpy(), ref["counters"].cpu().numpy()
+        cols = [0, 1, 2, 3, 4, 6, 7]
+        assert (c[:, cols] == r[:, cols]).all(), (L, N, eps, np.argwhere(c[:, cols] != r[:, cols])[:3].tolist())
+        assert (out["erased"].cpu().numpy() == ref["erased"].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("name", golden_names(variants=("bpf",)))
+def test_fixpoint_kernel_matches_reference_golden(E, name):
+    """The real reference's unlimited-iteration outputs (fixtures with max_it = 0 only)."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    if g.max_it:
+        pytest.skip("fixture with an iteration cap")
+    p, T, (d_adj, d_ch) = _golden_inputs(E, g)
+    out = E.full_bp_fixpoint(p, d_adj, d_ch, is_term=bool(m["is_term"]), want_erased=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for col, key in ((0, "ne"), (1, "be"), (2, "ee"), (3, "bee"), (7, "nch")):
+        assert (c[:, col] == g[key][:T]).all(), (name, key)
+    if g.has("erased"):
+        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
