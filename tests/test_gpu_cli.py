@@ -82,3 +82,19 @@ def test_bp_traj_and_sw_files(B, oracle, tmp_path):
         res, _ = O.decode_sw(O.Graph.from_vn_adj(po, A[t]), bits[t], 5, 4, 9, literal=True)
         ue += res["num_erasures"]; fe += res["num_erasures"] > 0
     assert int(row[9]) == 16 and int(row[10]) == ue and int(row[11]) == fe
+
+
+def test_bp_lim_iter_fixpoint_schedule_writes_the_same_rows(B, tmp_path):
+    """MAX_IT = 10^6 (the reference's "unlimited"): --schedule fixpoint must produce the very file the flooding schedule
+    produces — same frames consumed, same counters — on the glibc replay and on the Philox stream."""
+    for rng_args in (["--rng", "glibc", "--seed", "5"], ["--rng", "philox", "--seed", "9"]):
+        outs = []
+        for sched in ("flooding", "fixpoint"):
+            d = tmp_path / (sched + rng_args[1])
+            B.bp_lim_iter(["1", "0", "0", "1000000", "--L", "16", "--N", "200", "--num-points", "3", "--max-frames", "60",
+                           "--min-frame-err", "20", "--batch", "16", "--eps-ini", "0.47", "--outdir", str(d), "--quiet",
+                           "--schedule", sched] + rng_args)
+            files = sorted(os.listdir(d))
+            assert len(files) == 1
+            outs.append(open(d / files[0]).read())
+        assert outs[0] == outs[1] and len(outs[0].strip().split("\n")) == 4
