@@ -24,6 +24,7 @@ template <bool G>
 struct WideT {
     static constexpr bool kGlobal = G;
     static constexpr bool kHasDeg = true;          // the CN degree rides in the word (trajectory mode)
+    static constexpr bool kPacked16 = false;
     static __host__ __device__ int lds_words(int nk) { return G ? 0 : nk; }
     static __host__ __device__ int words(int nk) { return nk; }
     static __device__ __forceinline__ uint32_t ld(const uint32_t *st, int c)
@@ -61,6 +62,7 @@ using WideG = WideT<true>;
 struct Packed {     // two CNs per 32-bit word; CN c lives in half (c & 1) of word c >> 1
     static constexpr bool kGlobal = false;
     static constexpr bool kHasDeg = false;         // trajectory mode keeps the few degrees it needs in a side array
+    static constexpr bool kPacked16 = true;        // peel_fixpoint.h applies
     static __host__ __device__ int lds_words(int nk) { return (nk + 1) / 2; }
     static __host__ __device__ int words(int nk) { return (nk + 1) / 2; }
     static __device__ __forceinline__ void add(uint32_t *st, int c, const Vn &v, int i, int V, bool erased, bool)
