@@ -386,11 +386,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
         }
     }
     __syncthreads();
+    STAMP_DECL
+    STAMP(0);                                                       // channel + build
     const int nch = scal[S_NE];
 
     int removed = 0;
     PeelCtx x{L, V, C, n, cn_lim, qcap, adj, cn_state, U, fbits, q[0], q[1], &scal[S_PUSH], &scal[S_OVF]};
     const int rounds = peel_to_fixpoint<A16, BLOCK>(a, x, removed, [](int, int, bool one) { return one; });
+    STAMP(1);                                                       // peeling (barrier rounds + barrier-free phase)
     removed = wave_sum(removed);
     if (lane == 0 && removed) atomicAdd(&scal[S_REM], removed);
     __syncthreads();
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
         }
     }
     __syncthreads();
+    STAMP(2);                                                       // final counts + expurgation
+    STAMP_FLUSH();
     if (a.erased_out)
         for (int w = tid; w < nw; w += BLOCK) a.erased_out[(size_t)trial * nw + w] = U[w];
     if (tid == 0) {

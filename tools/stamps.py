@@ -37,5 +37,7 @@ show("sample_philox_kernel", ["clear", "keys+histogram", "scan", "group", "rank"
 out = E.full_bp(p, d_adj, d_ch)
 show("full_bp_kernel", ["clear+channel", "build", "release", "wave reductions", "barrier wait", "bookkeeping",
                         "final+expurgation"])
+out2 = E.full_bp_fixpoint(p, d_adj, d_ch)
+show("full_bp_fixpoint_kernel", ["channel+build", "peeling (rounds + barrier-free phase)", "final+expurgation"])
 it = out["counters"][:, 5].float().mean().item()
 print("mean iterations", it)
