@@ -27,6 +27,7 @@ p = E.make_params(4, 8, 50, 1000)
 T = 8192
 d_adj, d_ch = E.sample_philox(p, 1, 0, T, 0.48, adj16=True)
 timed("C2  full BP, unlimited (decode only)", lambda: E.full_bp(p, d_adj, d_ch), T)
+timed("C2  full BP, unlimited, fixpoint kernel (decode only)", lambda: E.full_bp_fixpoint(p, d_adj, d_ch), T)
 timed("C2  full BP, max 100 iterations", lambda: E.full_bp(p, d_adj, d_ch, max_it=100), T)
 timed("C2  full BP with trajectory rows (bp_traj mode)", lambda: E.full_bp(p, d_adj, d_ch, rows_cap=1024), T)
 timed("C2  square window W=20, 6/60 iterations", lambda: E.sw_bp(p, d_adj, d_ch, 20, 6, 60), T)
