@@ -7,10 +7,13 @@
 Same positional argv, same ε grid / stop rule / output files (names and row formats of `risultati`,
 BPF:458-519, and of the trajectory dump, BPT:988,1051,1145), but the ensemble size and grid — compile
 time #defines in the reference (BPF:22-67) — are options with the reference's values as defaults, the
-frames of an ε point are decoded in device batches, and the batches of a point are sharded over the
-ranks of a torch.distributed job (one process per GPU; the only exchange is an all-gather of the
-per-trial counter rows, 32 B per trial, so that the ordered stop rule `frame_err >= 1000` cuts at the
-same frame on every rank).
+frames of an ε point are decoded in device batches.  Under torch.distributed (one process per GPU) the work
+is sharded the way the reference is run on a cluster — one process per subset of ε points (NB cell 35:21-25,
+loop BPF:2111-2114): point `sim` belongs to rank `sim % world`, no collective on the data path, and after
+every wave of `world` points one all-reduce of the 9 run counters per point lets rank 0 append the rows in
+grid order.  With fewer points than ranks (or --shard frames) the frames of a point are split evenly over
+the ranks instead; the only exchange is then an all-gather of the per-trial counter rows (32 B per trial),
+so that the ordered stop rule `frame_err >= 1000` cuts at the same frame on every rank.
 
 Two sampling modes:
   * rng="philox" (default): codes and channels drawn on the device, counter-based, trial t of point s
@@ -111,12 +114,14 @@ class Simulator:
     """Batched Monte-Carlo driver around the device decoders."""
 
     def __init__(self, p, decoder="full", W=0, max_it=0, init_it=0, is_term=True, doped=(), batch=2048,
-                 rng="philox", seed=1, device=None, rows_cap=0, schedule="flooding"):
+                 rng="philox", seed=1, device=None, rows_cap=0, schedule="flooding", shard_frames=True):
         self.p, self.decoder, self.W, self.max_it, self.init_it = p, decoder, W, max_it, init_it
         self.schedule = schedule        # "fixpoint": unlimited full BP without the iteration count (1.2x faster)
         self.is_term, self.doped, self.batch, self.rng, self.seed = is_term, tuple(doped), batch, rng, seed
         self.rows_cap = rows_cap
         self.dist, self.rank, self.world = _dist()
+        if not shard_frames:                    # ε points are sharded by the caller: every point runs on one rank
+            self.dist, self.rank, self.world = None, 0, 1
         self.device = torch.device(device if device is not None else
                                    "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
         if rng == "glibc":
@@ -161,58 +166,80 @@ class Simulator:
             self.d_ch[:nb].copy_(torch.from_numpy(ch.view(np.int32)))
 
     # -- one ε point -------------------------------------------------------------------------------
+    @staticmethod
+    def split_round(frames_left, batch, world):
+        """Frames of one round and their even split over the ranks (contiguous ranges in frame order): a round
+        takes min(frames_left, world*batch) frames, rank r gets ⌈·⌉ or ⌊·⌋ of them — at the reference's defaults
+        (1000 frames per point, BPF:65) every rank of an 8-GPU job decodes 125 frames, none idles."""
+        R = min(frames_left, world * batch)
+        base, rem = divmod(R, world)
+        sizes = [base + (1 if r < rem else 0) for r in range(world)]
+        offs = [sum(sizes[:r]) for r in range(world)]
+        return R, sizes, offs
+
     def run_point(self, sim, eps, min_frame_err, max_frames, on_batch=None):
         """Frames 0,1,2,… of the point until frame_err >= min_frame_err or max_frames frames, in frame
-        order (BPF:2117-2144).  In every round rank r decodes the r-th of `world` consecutive batches;
-        the per-trial counter rows are all-gathered and accumulated in frame order on every rank, so all
-        ranks cut at the same frame.  on_batch(frame0, frames_used, result) sees this rank's batches."""
+        order (BPF:2117-2144).  Every round takes the next min(frames left, world·batch) frames and splits them
+        evenly over the ranks; the per-trial counter rows are all-gathered and accumulated in frame order on
+        every rank, so all ranks cut at the same frame.  The host looks at the run counters only in rounds in
+        which the stop rule could trip (frames so far + this round >= min_frame_err); other rounds stay
+        asynchronous.  on_batch(frame0, frames_used, result) sees this rank's batches."""
         p, B, W = self.p, self.batch, self.world
         i_frames, i_ferr, i_status = RUN_NAMES.index("frames"), RUN_NAMES.index("frame_err"), \
             E.COUNTER_NAMES.index("status")
         if self.rng == "glibc":
             self.glibc.new_point()
         run = self._new_run()
+        bad = torch.zeros((), dtype=torch.bool, device=run.device)
         frame0, consumed = 0, 0
         while frame0 < max_frames:
-            sizes = [max(0, min(B, max_frames - (frame0 + r * B))) for r in range(W)]
-            nb = sizes[self.rank]
+            R, sizes, offs = self.split_round(max_frames - frame0, B, W)
+            nb, off = sizes[self.rank], offs[self.rank]
             res = None
             snap = self.glibc.snapshot() if self.rng == "glibc" else None
             if nb:
-                self.fill_batch(sim, eps, frame0 + self.rank * B, nb)
+                self.fill_batch(sim, eps, frame0 + off, nb)
                 res = self.decode_batch(nb, want_rows=on_batch is not None and self.rows_cap > 0)
             if W > 1:
-                if nb < B:
-                    self.d_cnt[nb:].zero_()
-                gathered = [torch.empty_like(self.d_cnt) for _ in range(W)]
-                self.dist.all_gather(gathered, self.d_cnt)
+                m = max(sizes)
+                if nb < m:
+                    self.d_cnt[nb:m].zero_()
+                gathered = [torch.empty_like(self.d_cnt[:m]) for _ in range(W)]
+                self.dist.all_gather(gathered, self.d_cnt[:m].contiguous())
                 allcnt = torch.cat([g[:s] for g, s in zip(gathered, sizes)], dim=0).contiguous()
             else:
                 allcnt = self.d_cnt[:nb]
             self._accumulate(allcnt, run, min_frame_err)
-            r = run.cpu().numpy()
-            used_round = int(r[i_frames]) - consumed
-            consumed = int(r[i_frames])
-            if bool((allcnt[:used_round, i_status] != 0).any()):
-                # the reference aborts the process here (BPF:1035-1039)
-                print("ARGH! RECOVERED MORE VNs THAN deg-1 CNs! Aborting!")
-                raise SystemExit(-1)
+            can_trip = min_frame_err > 0 and frame0 + R >= min_frame_err
+            if can_trip:
+                r = run.cpu().numpy()
+                used_round = int(r[i_frames]) - consumed
+                consumed = int(r[i_frames])
+                stopped = r[i_ferr] >= min_frame_err
+            else:
+                used_round, stopped = R, False
+                consumed += R
+            bad |= (allcnt[:used_round, i_status] != 0).any()
             if on_batch is not None and nb:
-                on_batch(frame0 + self.rank * B, max(0, min(nb, used_round - sum(sizes[:self.rank]))), res)
-            stopped = min_frame_err > 0 and r[i_ferr] >= min_frame_err
+                on_batch(frame0 + off, max(0, min(nb, used_round - off)), res)
             if stopped and snap is not None and used_round < nb:
                 # the reference stops drawing at the tripping frame: rewind the stream to just after it
                 self.glibc.restore(snap)
                 self.glibc.next_frames(used_round, eps, self.doped)
-            frame0 += sum(sizes)
+            frame0 += R
             if stopped:
                 break
+        if bool(bad):
+            # the reference aborts the process at such a frame (BPF:1035-1039)
+            print("ARGH! RECOVERED MORE VNs THAN deg-1 CNs! Aborting!")
+            raise SystemExit(-1)
         return PointResult(eps, p.n, p.L, run.cpu().numpy())
 
 
-def _write_traj_rows(fh, rows, counters, nb):
+def _write_traj_rows(fh, rows, counters, nb, cols=4):
     """Per frame: one line per iteration `iter\\tdeg1\\trecovered\\tfirst_pos`, then an empty line
-    (BPT:988,1051,1145)."""
+    (BPT:988,1051,1145).  cols=3 drops the last column: the layout of the published `…L50_M2500…` files
+    (an older build of the program; read by NB cell 40:10-19 with a 3-column unpack)."""
     rows = rows.cpu().numpy()
     its = counters[:, E.COUNTER_NAMES.index("iterations")].cpu().numpy()
     out = []
@@ -221,7 +248,10 @@ def _write_traj_rows(fh, rows, counters, nb):
         if k > rows.shape[1]:
             raise RuntimeError(f"trajectory of {k} iterations exceeds rows_cap={rows.shape[1]}; raise --rows-cap")
         r = rows[t, :k]
-        out.append("".join("%d\t%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1], r[i, 2]) for i in range(k)))
+        if cols == 3:
+            out.append("".join("%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1]) for i in range(k)))
+        else:
+            out.append("".join("%d\t%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1], r[i, 2]) for i in range(k)))
         out.append("\n")
     fh.write("".join(out))
 
@@ -252,12 +282,49 @@ def run_program(prog, index, W, num_doped, max_it, extra, opts):
     elif prog == "bp_traj":
         is_term = bool(extra)
     dist, rank, world = _dist()
-    sim_obj = Simulator(p, decoder=decoder, W=W, max_it=(0 if prog == "bp_traj" else max_it), init_it=init_it,
+    # Sharding (module docstring): ε points over the ranks when there are at least as many points as ranks
+    # (the reference's own cluster model), else the frames of every point.
+    shard = getattr(opts, "shard", "auto")
+    if shard == "auto":
+        shard = "points" if (world > 1 and grid.num_points >= world and prog != "bp_traj") else "frames"
+    by_points = shard == "points" and world > 1
+    # the decoders' loop is do { … } while (iter < MaxNumIt) (BPF:1065, BPT:1076): at least one iteration runs
+    cap = max(1, max_it)
+    sim_obj = Simulator(p, decoder=decoder, W=W, max_it=cap, init_it=init_it,
                         is_term=is_term, doped=doped, batch=opts.batch, rng=opts.rng, seed=opts.seed,
-                        rows_cap=opts.rows_cap if prog == "bp_traj" else 0, schedule=getattr(opts, "schedule", "flooding"))
+                        rows_cap=opts.rows_cap if prog == "bp_traj" else 0, schedule=getattr(opts, "schedule", "flooding"),
+                        shard_frames=not by_points, device=getattr(opts, "device", None))
     outdir = opts.outdir
     os.makedirs(outdir, exist_ok=True)
     t0 = time.time()
+
+    def report(eps, point):
+        if rank == 0 and not opts.quiet:
+            r = point.run
+            print("%f %e %e %e   (f=%d, %.1fs)" % (eps, r["users_err"] / p.n / point.f, r["frame_err"] / point.f,
+                                                   r["block_err"] / p.L / point.f, point.f, time.time() - t0),
+                  flush=True)
+
+    if by_points:
+        # wave k = points [k·world, (k+1)·world): rank r runs point k·world + r alone, then one all-reduce of the
+        # run counters (NRUN int64 per point) hands the wave to rank 0, which appends the rows in grid order —
+        # finished waves survive a killed job like the reference's per-point fopen("a") (BPF:494-497).
+        path = os.path.join(outdir, result_filename(prog, p, W, max_it, init_it, index))
+        for sim0 in range(0, grid.num_points, world):
+            wave = torch.zeros((world, NRUN), dtype=torch.int64, device=sim_obj.device)
+            sim = sim0 + rank
+            if sim < grid.num_points:
+                point = sim_obj.run_point(sim, grid.eps(sim), grid.min_frame_err, grid.max_frames)
+                wave[rank] = torch.tensor([point.run[k] for k in RUN_NAMES], dtype=torch.int64, device=sim_obj.device)
+            dist.all_reduce(wave)
+            if rank == 0:
+                rows = wave.cpu().numpy()
+                for r in range(min(world, grid.num_points - sim0)):
+                    pt = PointResult(grid.eps(sim0 + r), p.n, p.L, rows[r])
+                    write_risultati(path, sim0 + r, pt)
+                    report(pt.eps, pt)
+        return 0
+
     for sim in range(grid.num_points):
         eps = grid.eps(sim)
         if prog == "bp_traj":
@@ -268,17 +335,13 @@ def run_program(prog, index, W, num_doped, max_it, extra, opts):
             path = os.path.join(outdir, traj_filename(p, eps, max_it, is_term, index))
             with open(path, "w") as fh:
                 def on_batch(frame0, used, res):
-                    _write_traj_rows(fh, res["rows"], res["counters"], used)
+                    _write_traj_rows(fh, res["rows"], res["counters"], used, cols=getattr(opts, "cols", 4))
                 point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames, on_batch=on_batch)
         else:
             point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames)
             if rank == 0:
                 write_risultati(os.path.join(outdir, result_filename(prog, p, W, max_it, init_it, index)), sim, point)
-        if rank == 0 and not opts.quiet:
-            r = point.run
-            print("%f %e %e %e   (f=%d, %.1fs)" % (eps, r["users_err"] / p.n / point.f, r["frame_err"] / point.f,
-                                                   r["block_err"] / p.L / point.f, point.f, time.time() - t0),
-                  flush=True)
+        report(eps, point)
     return 0
 
 
@@ -309,6 +372,13 @@ def _parser(prog):
     ap.add_argument("--schedule", choices=("flooding", "fixpoint"), default="flooding",
                     help="bp_lim_iter with MAX_IT >= 10^6: 'fixpoint' decodes to the same residual without walking "
                          "the flooding iterations (same files; no iteration statistics)")
+    ap.add_argument("--shard", choices=("auto", "points", "frames"), default="auto",
+                    help="multi-GPU: ε points over the ranks (the reference's cluster model; default when there are at "
+                         "least as many points as ranks) or the frames of every point")
+    if prog == "bp_traj":
+        ap.add_argument("--cols", type=int, choices=(3, 4), default=4,
+                        help="4: iter, deg1, recovered, first erased position (BPT:988,1051); 3: without the last "
+                             "(the published L50_M2500 files, NB cell 40)")
     ap.add_argument("--outdir", default=".")
     ap.add_argument("--quiet", action="store_true")
     return ap
@@ -341,14 +411,6 @@ def sw_lim_iter(argv=None):
 
 def bp_traj(argv=None):
     return main("bp_traj", argv)
-
-
-if __name__ == "__main__":
-    if len(sys.argv) >= 2 and sys.argv[1] == "sw":
-        sys.exit(streaming(sys.argv[2:]))
-    if len(sys.argv) < 2 or sys.argv[1] not in DEFAULTS:
-        raise SystemExit("usage: python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj|sw} ARGS…")
-    sys.exit(main(sys.argv[1], sys.argv[2:]))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -443,3 +505,11 @@ def streaming(argv=None):
         import torch.distributed as dist
         dist.destroy_process_group()
     return rc
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 2 and sys.argv[1] == "sw":
+        sys.exit(streaming(sys.argv[2:]))
+    if len(sys.argv) < 2 or sys.argv[1] not in DEFAULTS:
+        raise SystemExit("usage: python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj|sw} ARGS…")
+    sys.exit(main(sys.argv[1], sys.argv[2:]))

@@ -36,6 +36,8 @@ for e in EPS_TINY:
         (f"tiny_bpf_M5_L10_e{tag}_it3", "bpf", 5, 10, 32, 300, e, dict(dump=True, max_it=3)),
         (f"tiny_bpt_M5_L10_e{tag}_term", "bpt", 5, 10, 32, 500, e, dict(dump=True, is_term=1)),
         (f"tiny_bpt_M5_L10_e{tag}_trunc", "bpt", 5, 10, 32, 700, e, dict(dump=True, is_term=0)),
+        # bp_traj with a binding iteration cap (the published files are 500it / 1000it; BPT:1076, 2116)
+        (f"tiny_bpt_M5_L10_e{tag}_term_it3", "bpt", 5, 10, 32, 1500, e, dict(dump=True, is_term=1, max_it=3)),
         (f"tiny_bpw_M5_L10_e{tag}_W4_it3_init7", "bpw", 5, 10, 32, 900, e, dict(dump=True, W=4, max_it=3, init_it=7)),
         (f"tiny_bpw_M5_L10_e{tag}_W3_it2", "bpw", 5, 10, 32, 1100, e, dict(dump=True, W=3, max_it=2, init_it=0)),
         (f"tiny_bpfsw_M5_L10_e{tag}_W4_it3", "bpfsw", 5, 10, 32, 1300, e, dict(dump=True, W=4, max_it=3)),
@@ -62,6 +64,9 @@ SETS += [
     ("c2_bpf_M500_L50_e480_it100", "bpf", 500, 50, 12, 4000, 0.48, dict(max_it=100)),
     ("c2_bpt_M500_L50_e480_term", "bpt", 500, 50, 8, 5000, 0.48, dict(is_term=1)),
     ("c2_bpt_M500_L50_e460_trunc", "bpt", 500, 50, 8, 6000, 0.46, dict(is_term=0)),
+    ("c2_bpt_M500_L50_e480_term_it100", "bpt", 500, 50, 8, 6500, 0.48, dict(is_term=1, max_it=100)),
+    ("mid_bpt_M50_L20_e470_trunc_it5", "bpt", 50, 20, 24, 6600, 0.47, dict(is_term=0, max_it=5)),
+    ("mid_bpt_M50_L20_e490_term_it1", "bpt", 50, 20, 24, 6700, 0.49, dict(is_term=1, max_it=1)),
     ("c2_bpw_M500_L50_e465_W20_it6_init60", "bpw", 500, 50, 8, 7000, 0.465, dict(W=20, max_it=6, init_it=60)),
     ("c2_bpw_M500_L50_e470_W10_it20", "bpw", 500, 50, 6, 8000, 0.47, dict(W=10, max_it=20, init_it=0)),
     # bp_traj's shipped size (Def_M = 2500, BPT:25) and BASELINE config 4 (L=100, N=2000): beyond the LDS-resident kernels
@@ -71,6 +76,9 @@ SETS += [
     # whole-run replay: no re-seeding between frames, perm_code and RNG stream carry over (BPF:2117-2144)
     ("c2_bpf_M500_L50_e480_wholerun", "bpf", 500, 50, 6, 7, 0.48, dict(whole_run=True)),
     ("tiny_bpf_M5_L10_e480_wholerun", "bpf", 5, 10, 200, 7, 0.48, dict(whole_run=True)),
+    # bp_traj runs (one srandom, frames back to back) with a binding MAX_IT: what `bp_traj INDEX 0 0 MAX_IT IS_TERM` writes
+    ("tiny_bpt_M5_L10_e460_term_it3_wholerun", "bpt", 5, 10, 20, 77, 0.46, dict(whole_run=True, max_it=3, is_term=1)),
+    ("mid_bpt_M50_L20_e460_trunc_it6_wholerun", "bpt", 50, 20, 12, 78, 0.46, dict(whole_run=True, max_it=6, is_term=0)),
 ]
 
 

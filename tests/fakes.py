@@ -38,8 +38,10 @@ def numpy_accumulate(cnt, run, stop):
 
 
 class FakeSimulator(B.Simulator):
-    def __init__(self, p, batch, **kw):
+    def __init__(self, p, batch=8, **kw):
         self._frames = None
+        self.frames_decoded = 0                 # frames this rank decoded (sharding tests)
+        kw.pop("device", None)
         super().__init__(p, batch=batch, device="cpu", **kw)
 
     def _alloc(self):
@@ -47,6 +49,7 @@ class FakeSimulator(B.Simulator):
 
     def fill_batch(self, sim, eps, frame0, nb):
         self._frames = (sim, np.arange(frame0, frame0 + nb))
+        self.frames_decoded += nb
 
     def decode_batch(self, nb, want_rows=False):
         sim, idx = self._frames

@@ -51,6 +51,72 @@ def test_two_ranks_equal_one_rank():
         assert got[0][i] == ref and got[1][i] == ref, (cases[i], got[0][i], ref)
 
 
+def _program_worker(rank, world, port, outdir, shard, q):
+    """run_program (the body of main_terminated) with the device work faked: files written by rank 0."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fakes
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    made = []
+
+    class Sim(fakes.FakeSimulator):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            made.append(self)
+    B.Simulator = Sim
+    argv = ["2", "0", "0", "50", "--L", "10", "--N", "10", "--num-points", "5", "--max-frames", "1000",
+            "--min-frame-err", "1000", "--shard", shard, "--outdir", outdir, "--quiet", "--seed", "3"]
+    opts = B._parser("bp_lim_iter").parse_args(argv)
+    B.run_program("bp_lim_iter", opts.INDEX, opts.W, opts.NUM_DOPED, opts.MAX_IT, None, opts)
+    q.put((rank, made[0].frames_decoded))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_points_and_frames_sharding_write_the_single_rank_file(tmp_path):
+    """The ε grid sharded over the ranks (rank = point mod world, rows merged by rank 0 in grid order) and the frames of
+    every point split evenly over the ranks both write the file one rank writes — at the reference's defaults
+    (--batch 2048, 1000 frames per point) with non-zero work on every rank."""
+    ctx = mp.get_context("spawn")
+    port = 33500 + os.getpid() % 2000
+    texts, work = {}, {}
+    for k, (world, shard) in enumerate([(1, "auto"), (2, "points"), (2, "frames"), (2, "auto")]):
+        d = str(tmp_path / f"w{world}{shard}")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_program_worker, args=(r, world, port + 7 * k, d, shard, q)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        work[(world, shard)] = dict(q.get(timeout=120) for _ in range(world))
+        for pr in procs:
+            pr.join(timeout=120)
+            assert pr.exitcode == 0
+        files = sorted(os.listdir(d))
+        assert files == ["SC_LDPC_4_8_L10_M5_BP_SW0_50it_Random_BLER_2.dat"]
+        texts[(world, shard)] = open(os.path.join(d, files[0])).read()
+    one = texts[(1, "auto")]
+    assert len(one.strip().split("\n")) == 6
+    for key, t in texts.items():
+        assert t == one, key
+    assert work[(1, "auto")][0] == 5000
+    assert work[(2, "points")] == {0: 3000, 1: 2000} and work[(2, "auto")] == work[(2, "points")]
+    assert work[(2, "frames")] == {0: 2500, 1: 2500}            # 500 + 500 of every point's 1000 frames
+
+
+def test_split_round_gives_every_rank_work_at_the_defaults():
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    R, sizes, offs = B.Simulator.split_round(1000, 2048, 8)
+    assert R == 1000 and sizes == [125] * 8 and offs == [125 * r for r in range(8)]
+    R, sizes, offs = B.Simulator.split_round(10, 4, 3)
+    assert R == 10 and sizes == [4, 3, 3] and offs == [0, 4, 7]
+    R, sizes, offs = B.Simulator.split_round(100, 4, 3)
+    assert R == 12 and sizes == [4, 4, 4]
+
+
 def _stream_worker(rank, world, port, outdir, streams):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))

@@ -98,3 +98,34 @@ def test_bp_lim_iter_fixpoint_schedule_writes_the_same_rows(B, tmp_path):
             assert len(files) == 1
             outs.append(open(d / files[0]).read())
         assert outs[0] == outs[1] and len(outs[0].strip().split("\n")) == 4
+
+
+@pytest.mark.parametrize("name,argv", [
+    ("tiny_bpt_M5_L10_e460_term_it3_wholerun", ["4", "0", "0", "3", "1", "--L", "10", "--N", "10"]),
+    ("mid_bpt_M50_L20_e460_trunc_it6_wholerun", ["4", "0", "0", "6", "0", "--L", "20", "--N", "100"]),
+])
+def test_bp_traj_honours_max_it_like_the_reference(B, tmp_path, name, argv):
+    """`bp_traj INDEX W NUM_DOPED MAX_IT IS_TERM` with a binding MAX_IT (BPT:1076 `while (iter < MaxNumIt)`, BPT:2116;
+    the published files are the 500it / 1000it ones): the written file — name and text — equals what the REAL reference
+    wrote on the same srandom seed (fixture: its rows frame after frame, oracle/make_golden.py), in the 4-column layout
+    (BPT:988,1051) and, with --cols 3, in the layout of the published L50_M2500 files (NB cell 40:10-19)."""
+    from conftest import load_golden
+    g = load_golden(name)
+    m = g.meta
+    for cols in (4, 3):
+        d = tmp_path / f"c{cols}"
+        B.bp_traj(argv + ["--max-frames", str(g.T), "--min-frame-err", str(g.T), "--batch", "5", "--rng", "glibc",
+                          "--seed", str(m["seed0"]), "--cols", str(cols), "--outdir", str(d), "--quiet"])
+        kind = "terminated" if m["is_term"] else "truncated"
+        path = d / ("trajectories_0.4600_%s_SC_LDPC_4_8_L%d_M%d_BP_Full_%dit_Random_BLER_4.dat"
+                    % (kind, m["L"], m["CNsPos"], m["max_it"]))
+        exp = []
+        for t in range(g.T):
+            r = g.rows_of(t)
+            assert len(r) <= m["max_it"]
+            if cols == 4:
+                exp.append("".join("%d\t%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1], r[i, 2]) for i in range(len(r))) + "\n")
+            else:
+                exp.append("".join("%d\t%d\t%d\n" % (i, r[i, 0], r[i, 1]) for i in range(len(r))) + "\n")
+        assert open(path).read() == "".join(exp)
+    assert any(len(g.rows_of(t)) == m["max_it"] for t in range(g.T))        # the cap binds in these fixtures

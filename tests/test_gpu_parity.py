@@ -77,7 +77,7 @@ def test_whole_run_replay_matches_reference_run_counters(E, name):
     run_src = E.GlibcRun(p, m["seed0"])
     adj, ch = run_src.next_frames(g.T, m["eps"])
     d_adj, d_ch = E.to_device(adj, ch)
-    out = E.full_bp(p, d_adj, d_ch)
+    out = E.full_bp(p, d_adj, d_ch, max_it=g.max_it, is_term=bool(m.get("is_term", 1)))
     run = E.accumulate_run(out["counters"], E.new_run(), 0)
     torch.cuda.synchronize()
     r = dict(zip(E.RUN_NAMES, run.cpu().tolist()))

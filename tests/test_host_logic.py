@@ -1,6 +1,8 @@
 """Host orchestration of the bp_decoding mirror: file names and row formats (risultati, BPF:458-519),
 argv contract incl. the doped-position quirk (BPF:2083-2091), ε grid (BPF:55-61,301) and the ordered stop
 rule under batching (BPF:440-451, 2117-2144) — with the device work replaced by tests/fakes.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,3 +80,18 @@ def test_argv_quirk_first_doped_position_is_max_it(tmp_path, monkeypatch):
                    "--batch", "16", "--seed", "1", "--outdir", str(tmp_path), "--quiet"])
     assert seen["decoder"] == "sw" and seen["init_it"] == 3 and seen["W"] == 4       # INIT_IT 0 ⇒ MAX_IT (BPW:2101)
     assert (tmp_path / "SC_LDPC_4_8_L12_M5_BP_SW4_3it_3init_Random_BLER_0.dat").exists()
+
+
+def test_module_entry_points_parse_their_argv():
+    """`python -m fl_scaling_sc_ldpc_amd.bp_decoding {bp_lim_iter|sw_lim_iter|bp_traj|sw} --help` — the module entry, as
+    INTEGRATION.md documents it (the `sw` branch used to run before `streaming` was defined)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for prog in ("bp_lim_iter", "sw_lim_iter", "bp_traj", "sw"):
+        r = subprocess.run([sys.executable, "-m", "fl_scaling_sc_ldpc_amd.bp_decoding", prog, "--help"], cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "INDEX" in r.stdout, (prog, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-m", "fl_scaling_sc_ldpc_amd.bp_decoding", "nonsense"], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "usage" in r.stderr

@@ -82,7 +82,12 @@ def test_oracle_whole_run(oracle, name):
         L.orc_generate_code(C.byref(p), C.byref(rng), O._p(perm, C.c_int32), O._p(vn_adj, C.c_int32),
                             O._p(cn_ptr, C.c_int32), O._p(cn_adj, C.c_int32))
         L.orc_channel(C.byref(p), C.byref(rng), m["eps"], 0, None, O._p(chan, C.c_uint8))
-        res, erased, _ = O.decode_bp(O.Graph(p, vn_adj, cn_ptr, cn_adj), chan, max_it=g.max_it, literal=False)
+        res, erased, rows = O.decode_bp(O.Graph(p, vn_adj, cn_ptr, cn_adj), chan, max_it=g.max_it, literal=False,
+                                        is_term=m.get("is_term", 1), rows_cap=512 if g.has("rows") else 0)
+        if g.has("rows"):               # bp_traj runs: the rows the reference wrote, frame after frame
+            gr = g.rows_of(t)
+            assert len(rows) == len(gr) and (rows["deg1"] == gr[:, 0]).all() and (rows["recovered"] == gr[:, 1]).all() \
+                and (rows["first_pos"] == gr[:, 2]).all(), (name, t)
         assert int(chan.sum()) == int(g["nch"][t]), (name, t)
         assert (res["num_erasures"], res["num_blocks_err"], res["num_erasures_exp"], res["num_blocks_err_exp"]) == \
             tuple(int(g[k][t]) for k in ("ne", "be", "ee", "bee")), (name, t)
