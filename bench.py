@@ -99,6 +99,9 @@ def main():
                     help="two streams: the sampler of step k+1 beside the decoder of step k (default: one stream)")
     ap.add_argument("--no-overlap", action="store_true", help="(default) one stream: sample, then decode, then accumulate")
     ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")
+    ap.add_argument("--gen1", action="store_true",
+                    help="first-generation kernels: sampler that ranks every key + fixpoint decoder on 16-bit CN words "
+                         "(default: sampler_v2 + the 4-bits-per-CN decoder, which also reads the CN -> socket table)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +125,11 @@ def main():
     # k+1 beside the decoder of step k — worth +1 % now that each kernel fills a CU's wave slots on its own.
     a.no_overlap = not a.overlap
     nbuf = 1 if a.no_overlap else 2
+    gen2 = not (a.gen1 or a.flooding or a.adj32)
+    if gen2 and not E.cn16_supported(p):
+        raise SystemExit("bench.py: the second-generation kernels do not take this ensemble")
     d_adj = [torch.empty((B, p.n, p.dv), dtype=torch.int32 if a.adj32 else torch.int16, device=dev) for _ in range(nbuf)]
+    d_cn = [torch.empty((B, p.nk, p.dc), dtype=torch.int16, device=dev) if gen2 else None for _ in range(nbuf)]
     d_ch = [torch.empty((B, p.nw), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     d_cnt = [torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     run = E.new_run(dev)
@@ -144,7 +151,10 @@ def main():
             s_samp.wait_event(decoded[b])                   # buffer b is free once its previous decode has finished
             if e:
                 e[0].record(s_samp)
-            E.sample_philox(p, seed, trial0, B, EPS, out=(d_adj[b], d_ch[b]))
+            if gen2:
+                E.sample_philox_cn16(p, seed, trial0, B, EPS, out=(d_adj[b], d_cn[b], d_ch[b]))
+            else:
+                E.sample_philox(p, seed, trial0, B, EPS, out=(d_adj[b], d_ch[b]))
             if e:
                 e[1].record(s_samp)
             sampled[b].record(s_samp)
@@ -154,6 +164,8 @@ def main():
                 e[2].record(s_dec)
             if a.flooding:
                 E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
+            elif gen2:
+                E.full_bp_fixpoint_cn16(p, d_adj[b], d_cn[b], d_ch[b], counters=d_cnt[b])
             else:
                 E.full_bp_fixpoint(p, d_adj[b], d_ch[b], counters=d_cnt[b])
             if e:

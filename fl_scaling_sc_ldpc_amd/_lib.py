@@ -32,6 +32,8 @@ EXPORTS = (
     "scldpc_stream_state_bytes", "scldpc_stream_run_device",
     "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16", "scldpc_sample_philox_ensemble_device",
     "scldpc_full_bp_fixpoint_device", "scldpc_full_bp_fixpoint_device_adj16",
+    "scldpc_sample_philox_cn16_supported", "scldpc_sample_philox_device_cn16",
+    "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16",
 )
 
 
@@ -91,6 +93,10 @@ def lib():
     L.scldpc_sample_philox_ensemble_device.argtypes = [pp, i32, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device.argtypes = [pp, i32, vp, vp, i32, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device_adj16.argtypes = L.scldpc_full_bp_fixpoint_device.argtypes
+    L.scldpc_sample_philox_cn16_supported.argtypes = [pp]
+    L.scldpc_full_bp_cn16_supported.argtypes = [pp]
+    L.scldpc_sample_philox_device_cn16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
+    L.scldpc_full_bp_fixpoint_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes

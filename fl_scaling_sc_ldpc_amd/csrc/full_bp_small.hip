@@ -1,0 +1,385 @@
+// The fixpoint of unlimited flooding BP (decodeBP, BPF:900-1140) with 4 bits of LDS per check node — gfx950.
+//
+// full_bp.hip keeps [count | fold of the erased neighbours' ids] per CN (16 bits) so that a CN with one erased neighbour
+// names it without a lookup; the 52 KiB of CN words then limit a CU to two trials in flight, and the decoder is bound by
+// the latency of its ~230 dependent levels.  Here a CN keeps ONLY the count (a nibble): when it drops to
+// one, its dc neighbours are read from the CN -> VN table the second-generation sampler emits (sampler_v2.hip) and the
+// one neighbour whose bit in the erased-VN bitmap U is still set is the one to resolve.  A trial needs 13 + 6 KiB of
+// state + queues = 26 KiB, a 256-thread workgroup decodes it, and six trials share a CU: three times the trials in
+// flight for one more dependent gather per level.
+//
+// Safe without a barrier per level because every release claims its VN in U (atomic test-and-clear) BEFORE it decrements
+// the VN's CNs: whoever sees a CN's count reach one (its decrement returned two, or a scan read one) sees at most one
+// neighbour with its U bit still set — the unclaimed one — and if that neighbour is being released elsewhere at that
+// moment the bit is already clear and the entry is dropped (that release will take the count to zero).
+//
+// Outputs: the counters of scldpc_full_bp_fixpoint_device (everything decodeBP reports except the iteration count).
+// The size-2 stopping-set expurgation only looks at what the reference reports: the FIRST position with a positive
+// expurgated count (is_first_printed, BPF:1074, 1126-1132), so only that position's erased VNs are examined.
+#include "common.h"
+#include "kernel_util.h"
+
+namespace {
+
+using namespace scldpc_dev;
+
+enum { SC_NE = 0, SC_REM, SC_N0, SC_N1, SC_OVF, SC_Q, SC_N = 8 };
+
+struct SmArgs {
+    int L, V, C, n, nk, cn_lim, nw, ncw;            // ncw = words of 8 count nibbles
+    uint32_t magic_v, magic_c;
+    int kswitch;                                    // frontier width below which the waves go private
+    int off_U, off_q0, off_q1, off_pos, off_scal, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
+    const uint16_t *vn_adj16;                       // [T][n][4]   CN index local to its position
+    const uint16_t *cn_adj16;                       // [T][nk][8]  VNs of every CN (0xFFFF: none)
+    const uint32_t *chan;
+    int32_t *counters;
+    uint32_t *erased_out;
+};
+
+// Seven 4-wave workgroups per CU are 7 waves per SIMD: at most 96 SGPRs and 72 VGPRs per wave (MI355X_MICROARCH.md).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
+{
+    constexpr int kWaves = BLOCK / 64;
+    extern __shared__ uint32_t lds[];
+    uint32_t *cnt = lds;                                                 // nk nibbles
+    uint32_t *U = lds + a.off_U;
+    uint16_t *q[2] = {reinterpret_cast<uint16_t *>(lds + a.off_q0), reinterpret_cast<uint16_t *>(lds + a.off_q1)};
+    int *pos_cnt = reinterpret_cast<int *>(lds + a.off_pos);
+    int *pos_ss = pos_cnt + a.L;
+    int *scal = reinterpret_cast<int *>(lds + a.off_scal);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int trial = blockIdx.x;
+    const int n = a.n, nk = a.nk, cn_lim = a.cn_lim, nw = a.nw, V = a.V, C = a.C, L = a.L, qcap = a.qcap;
+    const uint2 *vrow = reinterpret_cast<const uint2 *>(a.vn_adj16) + (size_t)trial * n;
+    const uint4 *crow = reinterpret_cast<const uint4 *>(a.cn_adj16) + (size_t)trial * nk;
+    const uint32_t *ch = a.chan + (size_t)trial * nw;
+
+    // ---- channel bits, clear the counts -------------------------------------------------------------------------
+    for (int c = tid; c < a.ncw; c += BLOCK) cnt[c] = 0;
+    int ne_local = 0;
+    for (int w = tid; w < nw; w += BLOCK) {
+        uint32_t x = ch[w];
+        if (w == nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+        U[w] = x;
+        ne_local += __popc(x);
+    }
+    if (tid < SC_N) scal[tid] = 0;
+    for (int i = tid; i < 2 * L; i += BLOCK) pos_cnt[i] = 0;
+    __syncthreads();
+    ne_local = wave_sum(ne_local);
+    if (lane == 0 && ne_local) atomicAdd(&scal[SC_NE], ne_local);
+
+    // ---- build: every erased VN counts itself into its 4 CNs; rows are loaded unconditionally (coalesced 8-B loads) --
+    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {
+        uint2 r[4];
+        bool er[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * BLOCK;
+            er[u] = false;
+            if (j < n) { r[u] = vrow[j]; er[u] = (U[j >> 5] >> (j & 31)) & 1u; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * BLOCK;
+            if (er[u]) {
+                const int base = (int)__umulhi((uint32_t)j, a.magic_v) * C;
+                const int c0 = base + (int)(r[u].x & 0xFFFFu), c1 = base + C + (int)(r[u].x >> 16);
+                const int c2 = base + 2 * C + (int)(r[u].y & 0xFFFFu), c3 = base + 3 * C + (int)(r[u].y >> 16);
+                atomicAdd(&cnt[c0 >> 3], 1u << ((c0 & 7) * 4));
+                atomicAdd(&cnt[c1 >> 3], 1u << ((c1 & 7) * 4));
+                atomicAdd(&cnt[c2 >> 3], 1u << ((c2 & 7) * 4));
+                atomicAdd(&cnt[c3 >> 3], 1u << ((c3 & 7) * 4));
+            }
+        }
+    }
+    __syncthreads();
+    STAMP_DECL
+    STAMP(0);                                                            // channel + build
+    const int nch = scal[SC_NE];
+
+    // ---- one release step: CN c is believed to have exactly one erased neighbour -----------------------------------
+    // out[i] = 1 + the CN on edge i of the released VN if this release left it with one erased neighbour, else 0
+    int removed = 0;
+    auto step = [&](int c, uint32_t (&out)[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        const uint4 s4 = crow[c];
+        const uint32_t jk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
+                                s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
+        uint32_t wd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) wd[k] = U[min(jk[k] >> 5, (uint32_t)nw - 1u)];      // 0xFFFF (no VN): any word, masked below
+        int j = -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (jk[k] != 0xFFFFu && ((wd[k] >> (jk[k] & 31u)) & 1u)) j = (int)jk[k];
+        if (j < 0) return;                                               // its last neighbour is being released elsewhere
+        const uint2 r = vrow[j];                                         // issued before the claim: overlaps its round trip
+        const uint32_t bit = 1u << (j & 31);
+        if (!(atomicAnd(&U[j >> 5], ~bit) & bit)) return;
+        removed++;
+        const int base = (int)__umulhi((uint32_t)j, a.magic_v) * C;
+        const int cc[4] = {base + (int)(r.x & 0xFFFFu), base + C + (int)(r.x >> 16),
+                           base + 2 * C + (int)(r.y & 0xFFFFu), base + 3 * C + (int)(r.y >> 16)};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = atomicSub(&cnt[cc[i] >> 3], 1u << ((cc[i] & 7) * 4));
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (((o[i] >> ((cc[i] & 7) * 4)) & 15u) == 2u && cc[i] < cn_lim) out[i] = (uint32_t)cc[i] + 1u;
+    };
+
+    // ---- peel: barrier rounds over a shared queue while the frontier is wide (a scan opens the run and repairs an
+    //      overflow), then every wave runs the CNs its own releases create from a private queue, level after level ----
+    const int kSwitch = a.kswitch;
+    const int wcap = (qcap / kWaves) & ~1, half_cap = wcap / 2;
+    int rounds = 0, ncur = 0;
+    bool scan = true;
+    for (;;) {
+        uint16_t *qc = q[rounds & 1], *qn = q[(rounds + 1) & 1];
+        if (scan) {
+            // every CN < cn_lim whose count is one right now, compacted into qc
+            for (int w0 = wave * 64; w0 < a.ncw; w0 += BLOCK) {
+                const int w = w0 + lane;
+                uint32_t z = 0;
+                if (w < a.ncw) {
+                    const uint32_t y = cnt[w] ^ 0x11111111u;             // nibble == 1  <=>  zero nibble of y
+                    z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+                    if (w * 8 + 8 > cn_lim) {                            // the word that holds cn_lim: drop the CNs beyond it
+                        const int keep = cn_lim - w * 8;
+                        z = keep <= 0 ? 0u : (z & ((1u << (4 * keep)) - 1u));
+                    }
+                }
+                const int mine = __popc(z);
+                const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (tot == 0) continue;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scal[SC_Q], tot);
+                base = __builtin_amdgcn_readfirstlane(base);
+                int idx = base + incl - mine;
+                while (z) {
+                    const int k = (__ffs((int)z) - 1) >> 2;
+                    z &= z - 1;
+                    if (idx < qcap) qc[idx] = (uint16_t)(w * 8 + k);
+                    idx++;
+                }
+            }
+            __syncthreads();
+            ncur = scal[SC_Q];
+            if (ncur > qcap) { ncur = qcap; if (tid == 0) scal[SC_OVF] = 1; }      // the rest: next scan
+            __syncthreads();
+        }
+        if (tid == 0) { scal[SC_Q] = 0; scal[SC_N0 + ((rounds + 1) & 1)] = 0; }
+        int *push = &scal[SC_N0 + (rounds & 1)];
+        bool overflow = false;
+        if (ncur > kSwitch || half_cap < 64) {
+            for (int k0 = wave * 64; k0 < ncur; k0 += BLOCK) {
+                uint32_t out[4] = {0, 0, 0, 0};
+                if (k0 + lane < ncur) step((int)qc[k0 + lane], out);
+                {   // append: one prefix scan + one LDS atomic per wave for all four edges
+                    const int mine = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+                    const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                    const int tot = __builtin_amdgcn_readlane(incl, 63);
+                    if (tot) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(push, tot);
+                        int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (out[i]) { if (idx < qcap) qn[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
+                    }
+                }
+            }
+        } else {
+            // private phase: wave w takes entries w, w + kWaves, … into its own part of qn and runs to exhaustion
+            uint16_t *mine = qn + wave * wcap;
+            int cntw = (ncur - wave + kWaves - 1) / kWaves, cur = 0;
+            if (cntw < 0) cntw = 0;
+            if (lane < cntw) mine[lane] = qc[wave + lane * kWaves];
+            while (cntw > 0) {
+                uint16_t *src = mine + cur * half_cap, *dst = mine + (cur ^ 1) * half_cap;
+                int ncnt = 0;
+                for (int b0 = 0; b0 < cntw; b0 += 64) {
+                    uint32_t out[4] = {0, 0, 0, 0};
+                    if (b0 + lane < cntw) step((int)src[b0 + lane], out);
+                    {   // append: wave-synchronous, no atomics
+                        const int mine_n = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+                        const int incl = (int)wave_inclusive_scan((uint32_t)mine_n);
+                        int idx = ncnt + incl - mine_n;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (out[i]) { if (idx < half_cap) dst[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
+                        ncnt += __builtin_amdgcn_readlane(incl, 63);
+                    }
+                }
+                cntw = min(ncnt, half_cap);
+                cur ^= 1;
+            }
+        }
+        if (overflow) scal[SC_OVF] = 1;
+        __syncthreads();
+        rounds++;
+        const int pushed = *push;
+        scan = scal[SC_OVF] != 0;            // a full queue dropped CNs: find them by a scan
+        __syncthreads();
+        if (tid == 0) scal[SC_OVF] = 0;
+        ncur = scan ? 0 : min(pushed, qcap);
+        if (!scan && ncur == 0) break;
+    }
+    STAMP(1);                                                            // peeling
+    removed = wave_sum(removed);
+    if (lane == 0 && removed) atomicAdd(&scal[SC_REM], removed);
+    __syncthreads();
+    const int ne = nch - scal[SC_REM];
+
+    // ---- erased VNs per position (word w of U may straddle two positions) --------------------------------------------
+    int be = 0, ee = 0, bee = 0;
+    if (ne > 0) {
+        for (int w = tid; w < nw; w += BLOCK) {
+            uint32_t x = U[w];
+            int p0 = (int)__umulhi((uint32_t)(w * 32), a.magic_v);
+            int room = (p0 + 1) * V - w * 32;                            // bits of this word left in position p0
+            while (x) {
+                const uint32_t lo = room >= 32 ? x : (x & ((1u << room) - 1u));
+                if (lo) atomicAdd(&pos_cnt[p0], __popc(lo));
+                x = room >= 32 ? 0u : (x >> room);
+                p0++;
+                room = V;
+            }
+        }
+        __syncthreads();
+        // ---- size-2 stopping sets (BPF:1067-1133) of the first failing position(s) only ----------------------------
+        int q0 = 0;
+        for (;;) {
+            while (q0 < L && pos_cnt[q0] == 0) q0++;
+            if (q0 >= L) break;
+            for (int t = tid; t < V; t += BLOCK) {
+                const int j = q0 * V + t;
+                if (!((U[j >> 5] >> (j & 31)) & 1u)) continue;
+                const uint2 r = vrow[j];
+                const int base = q0 * C;
+                const int cc[4] = {base + (int)(r.x & 0xFFFFu), base + C + (int)(r.x >> 16),
+                                   base + 2 * C + (int)(r.y & 0xFFFFu), base + 3 * C + (int)(r.y >> 16)};
+                bool pair = true;
+#pragma unroll
+                for (int i = 0; i < 4; i++) pair = pair && ((cnt[cc[i] >> 3] >> ((cc[i] & 7) * 4)) & 15u) == 2u;
+                if (!pair) continue;
+                int partner = -1;
+                for (int i = 0; i < 4 && pair; i++) {                    // the other erased neighbour of each CN
+                    const uint4 s4 = crow[cc[i]];
+                    const uint32_t jk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
+                                            s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
+                    int other = -1;
+                    for (int k = 0; k < 8; k++) {
+                        const int j2 = (int)jk[k];
+                        if (j2 != 0xFFFF && j2 != j && ((U[j2 >> 5] >> (j2 & 31)) & 1u)) other = j2;
+                    }
+                    if (other < 0 || (i > 0 && other != partner)) pair = false;
+                    partner = other;
+                }
+                if (pair && (int)__umulhi((uint32_t)partner, a.magic_v) == q0) atomicAdd(&pos_ss[q0], 1);
+            }
+            __syncthreads();
+            const int e = pos_cnt[q0] - pos_ss[q0];
+            if (e > 0) { ee = e; bee = 1; break; }                       // only the FIRST such position (BPF:1126-1132)
+            q0++;
+        }
+        for (int pos = 0; pos < L; pos++) be += pos_cnt[pos] > 0;
+    }
+    STAMP(2);                                                            // per-position counts + expurgation
+    STAMP_FLUSH();
+    if (a.erased_out)
+        for (int w = tid; w < nw; w += BLOCK) a.erased_out[(size_t)trial * nw + w] = U[w];
+    if (tid == 0) {
+        int32_t *o = a.counters + (size_t)trial * SCLDPC_NCOUNTERS;
+        o[SCLDPC_C_NUM_ERASURES] = ne;
+        o[SCLDPC_C_NUM_BLOCKS_ERR] = be;
+        o[SCLDPC_C_NUM_ERASURES_EXP] = ee;
+        o[SCLDPC_C_NUM_BLOCKS_ERR_EXP] = bee;
+        o[SCLDPC_C_NUM_ERASURES_P1] = 0;
+        o[SCLDPC_C_ITERATIONS] = rounds;                                 // barrier rounds, NOT flooding iterations
+        o[SCLDPC_C_STATUS] = 0;
+        o[SCLDPC_C_CHANNEL_ERASURES] = nch;
+    }
+}
+
+int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_cu)
+{
+    const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
+    a->L = p->L; a->V = p->vns_pos; a->C = p->cns_pos; a->n = n; a->nk = nk;
+    a->cn_lim = is_term ? nk : p->L * p->cns_pos;                        // BPT:944-948
+    a->nw = (n + 31) / 32; a->ncw = (nk + 7) / 8;
+    int off = 0;
+    auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
+    take(a->ncw);
+    a->off_U = take(a->nw);
+    a->off_pos = take(2 * p->L);
+    a->off_scal = take(SC_N);
+    const int budget = scldpc::kMaxLdsBytes / per_cu / 4 - 128;           // words per workgroup
+    int qwords = ((budget - off) / 2) & ~3;                              // per queue; two uint16 entries per word
+    if (qwords > 2048) qwords = 2048;
+    if (qwords < 128) return -1;
+    a->qcap = 2 * qwords;
+    a->off_q0 = take(qwords);
+    a->off_q1 = take(qwords);
+    a->total = off;
+    return 0;
+}
+
+int g_block = 256, g_per_cu = 7, g_kswitch = 128;        // tuning knobs (tools/ab_v2.py): scldpc_debug_small_cfg
+
+}  // namespace
+
+extern "C" int scldpc_debug_small_cfg(int block, int per_cu, int kswitch)
+{
+    if (block != 64 && block != 128 && block != 256 && block != 512) return -1;
+    g_block = block; g_per_cu = per_cu; g_kswitch = kswitch;
+    return 0;
+}
+
+// 1 when scldpc_full_bp_fixpoint_device_cn16 takes this ensemble
+extern "C" int scldpc_full_bp_cn16_supported(const scldpc_code_params *p)
+{
+    if (scldpc::check_params(p)) return 0;
+    SmArgs a{};
+    uint32_t m;
+    return p->dv == 4 && p->dc == 8 && p->cns_pos <= 65536 && scldpc::nk_of(p) <= 65536 && scldpc::n_of(p) < 65535 &&
+           make_args(p, 1, &a, 4) == 0 && scldpc::magic_of(p->vns_pos, scldpc::n_of(p) + 32, &m) &&
+           scldpc::magic_of(p->cns_pos, scldpc::nk_of(p), &m);
+}
+
+extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntrials,
+                                                   const uint16_t *d_vn_adj16, const uint16_t *d_cn_adj16,
+                                                   const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
+                                                   uint32_t *d_erased_bits, void *stream)
+{
+    const char *who = "scldpc_full_bp_fixpoint_device_cn16";
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (!scldpc_full_bp_cn16_supported(p))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 65536 CNs and fewer than 65535 VNs per trial", who);
+    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj16 || !d_cn_adj16 || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
+    if (ntrials == 0) return SCLDPC_OK;
+    SmArgs a{};
+    int per_cu = g_per_cu;                                               // workgroups per CU the LDS carve aims at
+    while (per_cu > 1 && make_args(p, is_term, &a, per_cu) != 0) per_cu--;
+    if (make_args(p, is_term, &a, per_cu) != 0)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the CN counts and VN bits do not fit the LDS", who);
+    scldpc::magic_of(p->vns_pos, a.n + 32, &a.magic_v);
+    scldpc::magic_of(p->cns_pos, a.nk, &a.magic_c);
+    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
+    a.counters = d_counters; a.erased_out = d_erased_bits;
+    a.kswitch = g_kswitch;
+    void (*kern)(const SmArgs) = g_block == 64 ? full_bp_small_kernel<64> : g_block == 128 ? full_bp_small_kernel<128>
+                                 : g_block == 512 ? full_bp_small_kernel<512> : full_bp_small_kernel<256>;
+    const size_t lds_bytes = 4u * (size_t)a.total;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(g_block), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}

@@ -15,6 +15,7 @@
 // back so that a host loop can chain trials like the reference's single stream) or a per-trial Philox counter.
 #include "common.h"
 #include "kernel_util.h"
+#include "philox.h"
 
 namespace {
 
@@ -38,18 +39,7 @@ struct Args {
     int32_t *out;                   // [T][4]: #erased, #picked, last r1, steps executed with a pick
 };
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+using scldpc_dev::philox4x32_10;
 
 // G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. the notebook's N = 10000)
 template <int DV, bool A16, bool G, bool D1G>

@@ -1,0 +1,296 @@
+// Throughput-mode sampler, second generation (gfx950) — the (dv = 4, dc = 8) Olmos chain with up to 4096 sockets per
+// CN position, i.e. the BASELINE ensemble (4,8,L,N <= 1024).  Same law and same Philox keys as sampler.hip
+// (generate_code / channel_doped, BPF:1656-1761, 1547-1574): its vn_adj16 and channel words are bit for bit those of
+// scldpc_sample_philox_device_adj16 and of the CPU twin.  Two differences:
+//
+//  * Ranking only where it matters.  The CN of a socket is rank / dc, so a bucket of the key histogram whose rank range
+//    [g0, g1) lies inside one block of dc ranks gives all its keys the same CN whatever their order: CN = g0 / dc, no
+//    comparison, no grouping.  Only the keys of buckets that straddle a multiple of dc (3 % of the keys at 0.24 keys per
+//    bucket) are written out (packed [key's low bits | socket], one word) and compared with their bucket mates.
+//    sampler.hip groups and ranks every key: 61 % of its cycles (profiles/r01_stamps.txt).
+//  * The CN -> VN table comes with it: cn_adj16[trial][CN][dc] = the VNs attached to every CN (global VN index, which
+//    needs n < 65535), which is just the inverse of the ranking: rank r holds socket s = dv*t + i, i.e. edge i of VN t
+//    of position CNpos - i; at the chain ends sockets of positions outside [0, L) stand for no VN (the reference leaves
+//    such CNs with a lower degree, BPF:1703-1716) and read 0xFFFF.  Within a CN the order is unspecified (arrival order
+//    of the histogram atomics for non-straddling buckets): consumers treat the dc entries as a set.
+//    full_bp_small.hip decodes from (vn_adj16, cn_adj16) with 4 bits of LDS per CN.
+#include "common.h"
+#include "kernel_util.h"
+#include "philox.h"
+
+namespace {
+
+using scldpc_dev::philox4x32_10;
+using scldpc_dev::wave_inclusive_scan;
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxDoped = 32;
+constexpr int kWorkCap = 512;           // keys of buckets that span two CNs, per position (expected: 0.03 * S <= 123)
+
+struct S2Args {
+    int L, cns_pos, vns_pos, n, S, D, nb, shift, sbits, nw;
+    int ndoped;
+    int doped[kMaxDoped];
+    uint32_t seed_lo, seed_hi;
+    unsigned long long trial0;
+    uint32_t thresh;                    // erased iff (draw >> 1) < thresh
+    int off_gpk, off_win, off_stage, off_wsum;      // LDS offsets in 32-bit words
+    uint16_t *vn_adj16;                 // uint16 [T][n][4], CN index local to its position
+    uint16_t *cn_adj16;                 // uint16 [T][D*cns_pos][8] VNs of every CN (0xFFFF: none), or null
+    uint32_t *chan;
+};
+
+// ROWS = 64-counter rows of the histogram each wave scans (nb / 1024)
+template <int ROWS>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_v2_kernel(const S2Args a)
+{
+    constexpr int DV = 4, DC_SHIFT = 3;
+    extern __shared__ uint32_t lds[];
+    uint32_t *hist = lds;                                               // nb words of four nibble-wide bucket counters
+    uint32_t *gpk = lds + a.off_gpk;                                    // S words: packed keys of straddling buckets
+    uint16_t *win = reinterpret_cast<uint16_t *>(lds + a.off_win);      // ring of dv x S CN-local ids
+    uint16_t *stage = reinterpret_cast<uint16_t *>(lds + a.off_stage);  // the S sockets' VNs in rank order (CN -> VNs)
+    uint32_t *wsum = lds + a.off_wsum;                                  // 16 wave totals + the worklist counter
+    uint32_t *wl = wsum + 32;                                           // worklist: 2 words per key of a straddling bucket
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long trial = a.trial0 + blockIdx.x;
+    const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
+    const int S = a.S, nb = a.nb;
+    const int ncalls = S >> 2;                                          // S % 4 == 0 (checked on the host)
+    const int kshift = a.shift - 2;                                     // key >> kshift = fine bucket
+    const uint32_t lowmask = (1u << kshift) - 1u;
+    const bool mine4 = tid < ncalls;                                    // this thread owns sockets 4*tid .. 4*tid+3
+
+    // hist word = [exclusive prefix:16 | n3:4 | n2:4 | n1:4 | n0:4]: four nibble-wide bucket counters in the low half
+    // (the atomic's return value is the key's arrival slot), the scan's prefix ORed into the high half.  Thread t owns
+    // words t*ROWS .. t*ROWS+ROWS-1 (one wide LDS access).
+    auto nib_sum = [](uint32_t x) {                                     // sum of the four nibbles of the low half
+        const uint32_t v = (x & 0x0F0Fu) + ((x >> 4) & 0x0F0Fu);
+        return (v + (v >> 8)) & 0xFFu;
+    };
+    STAMP_DECL
+    for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
+    if (tid == 0) wsum[kWaves] = 0;
+    __syncthreads();
+    for (int p = 0; p < a.D; p++) {
+        STAMP(0);
+        // ---- keys + bucket histogram
+        uint32_t key[4], slot[4], crowded = 0;
+        {
+            uint32_t r[4] = {0, 0, 0, 0};
+            if (mine4) philox4x32_10((uint32_t)tid, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                key[u] = r[u];
+                slot[u] = 0;
+                if (mine4) {
+                    const uint32_t b = r[u] >> kshift, sh = (b & 3u) * 4u;
+                    slot[u] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFu;
+                    crowded = max(crowded, slot[u]);
+                }
+            }
+        }
+        if (crowded >= 15u) __builtin_trap();                           // a bucket count must fit its nibble (never happens:
+        __syncthreads();                                                // 0.24 keys per bucket on average)
+        STAMP(1);
+
+        // ---- exclusive scan of the bucket counts: every thread scans its ROWS words, the wave scans the thread totals
+        //      (DPP), the 16 wave totals meet in wsum; the global prefix goes into the words' high halves
+        {
+            uint32_t x[ROWS], v[ROWS], tot = 0;
+            if constexpr (ROWS == 4) { const uint4 q = reinterpret_cast<const uint4 *>(hist)[tid]; x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
+            else if constexpr (ROWS == 2) { const uint2 q = reinterpret_cast<const uint2 *>(hist)[tid]; x[0] = q.x; x[1] = q.y; }
+            else x[0] = hist[tid];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { v[r] = nib_sum(x[r]); tot += v[r]; }
+            const uint32_t inc = wave_inclusive_scan(tot);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            const uint32_t wt = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t winc = wave_inclusive_scan(wt);
+            uint32_t pre = inc - tot + (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { x[r] |= pre << 16; pre += v[r]; }
+            if constexpr (ROWS == 4) reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(x[0], x[1], x[2], x[3]);
+            else if constexpr (ROWS == 2) reinterpret_cast<uint2 *>(hist)[tid] = make_uint2(x[0], x[1]);
+            else hist[tid] = x[0];
+        }
+        __syncthreads();
+        STAMP(2);
+
+        // ---- classify: every key gets rank g0 + arrival slot — any bijection onto its bucket's ranks gives the right CN
+        //      (g0 / dc) when the bucket lies inside one block of dc ranks.  CN ids go into the ring, VNs into the
+        //      rank-ordered stage.  Keys of buckets that span two CNs (3 %) are also put on a worklist for their true rank.
+        uint16_t *wp = win + (size_t)(p & 3) * S;
+        {
+            uint32_t h[4], rk[4], g0a[4], cnta[4], smask = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) h[u] = hist[mine4 ? (key[u] >> kshift) >> 2 : 0u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k4 = ((key[u] >> kshift) & 3u) * 4u, x = h[u];
+                const uint32_t below = x & ((1u << k4) - 1u);            // the counters of the word's lower buckets
+                g0a[u] = (x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu);
+                cnta[u] = (x >> k4) & 0xFu;
+                rk[u] = g0a[u] + slot[u];
+                if (mine4 && ((g0a[u] + cnta[u] - 1u) >> DC_SHIFT) != (g0a[u] >> DC_SHIFT)) smask |= 1u << u;
+            }
+            while (smask) {                                             // rare (3 % of the keys): one short divergent loop
+                const uint32_t u = (uint32_t)__ffs((int)smask) - 1u;
+                smask &= smask - 1u;
+                const uint32_t ky = u == 0 ? key[0] : u == 1 ? key[1] : u == 2 ? key[2] : key[3];
+                const uint32_t sl = u == 0 ? slot[0] : u == 1 ? slot[1] : u == 2 ? slot[2] : slot[3];
+                const uint32_t g0 = u == 0 ? g0a[0] : u == 1 ? g0a[1] : u == 2 ? g0a[2] : g0a[3];
+                const uint32_t cnt = u == 0 ? cnta[0] : u == 1 ? cnta[1] : u == 2 ? cnta[2] : cnta[3];
+                const uint32_t pk = ((ky & lowmask) << a.sbits) | ((uint32_t)tid * 4u + u);
+                gpk[g0 + sl] = pk;
+                const int e = atomicAdd(reinterpret_cast<int *>(&wsum[kWaves]), 1);
+                if (e < kWorkCap) { wl[2 * e] = g0 | (cnt << 16) | (sl << 20); wl[2 * e + 1] = pk; }
+            }
+            if (mine4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)                             // socket 4*tid + u is edge u of VN tid of position p - u (BPF:1712)
+                    stage[rk[u]] = (unsigned)(p - u) < (unsigned)a.L ? (uint16_t)((p - u) * a.vns_pos + tid) : (uint16_t)0xFFFFu;
+                uint2 v;
+                v.x = (rk[0] >> DC_SHIFT) | ((rk[1] >> DC_SHIFT) << 16); v.y = (rk[2] >> DC_SHIFT) | ((rk[3] >> DC_SHIFT) << 16);
+                *reinterpret_cast<uint2 *>(wp + tid * 4) = v;
+            }
+        }
+        __syncthreads();
+        STAMP(3);
+
+        // ---- the worklist: true rank among the bucket mates; counters cleared for the next position
+        if constexpr (ROWS == 4) reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(0, 0, 0, 0);
+        else if constexpr (ROWS == 2) reinterpret_cast<uint2 *>(hist)[tid] = make_uint2(0, 0);
+        else hist[tid] = 0;
+        {
+            const int nwork = (int)wsum[kWaves];
+            if (nwork > kWorkCap) __builtin_trap();                     // 3 % of S on average (<= 123 keys); the list holds 512
+            for (int e = tid; e < nwork; e += kThreads) {
+                const uint32_t ea = wl[2 * e], pk = wl[2 * e + 1];
+                const uint32_t g0 = ea & 0xFFFFu, cnt = (ea >> 16) & 0xFu, sl = ea >> 20;
+                uint32_t r = g0;
+                for (uint32_t m = 0; m < cnt; m++)
+                    if (m != sl) r += gpk[g0 + m] < pk;
+                const uint32_t sck = pk & ((1u << a.sbits) - 1u), t = sck >> 2, u = sck & 3u;
+                stage[r] = (unsigned)(p - (int)u) < (unsigned)a.L ? (uint16_t)((p - (int)u) * a.vns_pos + (int)t) : (uint16_t)0xFFFFu;
+                wp[sck] = (uint16_t)(r >> DC_SHIFT);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) wsum[kWaves] = 0;                                  // read again only after the next two barriers
+        STAMP(4);
+
+        // ---- VN position q = p-dv+1 now has all its dv permutations in the ring (BPF:1703-1716); CN position p its sockets
+        const int qpos = p - (DV - 1);
+        if (qpos >= 0) {
+            for (int t = tid; t < a.vns_pos; t += kThreads) {
+                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
+                const uint32_t l0 = win[(size_t)((qpos + 0) & 3) * S + 4 * t + 0];
+                const uint32_t l1 = win[(size_t)((qpos + 1) & 3) * S + 4 * t + 1];
+                const uint32_t l2 = win[(size_t)((qpos + 2) & 3) * S + 4 * t + 2];
+                const uint32_t l3 = win[(size_t)((qpos + 3) & 3) * S + 4 * t + 3];
+                uint2 v;
+                v.x = l0 | (l1 << 16); v.y = l2 | (l3 << 16);
+                reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
+            }
+        }
+        if (a.cn_adj16) {
+            uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)blockIdx.x * a.D + p) * (size_t)(S >> 2);
+            const uint2 *src = reinterpret_cast<const uint2 *>(stage);
+            for (int w = tid; w < (S >> 2); w += kThreads) dst[w] = src[w];
+        }
+        STAMP(5);
+    }
+
+    // ---- channel: 32 VNs per output word, 8 Philox calls
+    uint32_t *chan = a.chan + (size_t)blockIdx.x * a.nw;
+    for (int w = tid; w < a.nw; w += kThreads) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(w * 8 + c), 0x80000000u, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) word |= (uint32_t)((r[u] >> 1) < a.thresh) << (c * 4 + u);
+        }
+        const int j0 = w * 32;
+        if (j0 + 32 > a.n) word &= (1u << (a.n - j0)) - 1u;
+        for (int d = 0; d < a.ndoped; d++) {                            // doped positions are never erased (BPF:1566-1573)
+            const int lo = max(a.doped[d] * a.vns_pos, j0) - j0, hi = min((a.doped[d] + 1) * a.vns_pos, j0 + 32) - j0;
+            if (lo < hi) word &= ~(((hi - lo) == 32 ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << lo);
+        }
+        chan[w] = word;
+    }
+    STAMP(6);
+    STAMP_FLUSH();
+}
+
+}  // namespace
+
+// 1 when scldpc_sample_philox_device_cn16 takes this ensemble, else 0 (callers then use scldpc_sample_philox_device_adj16)
+extern "C" int scldpc_sample_philox_cn16_supported(const scldpc_code_params *p)
+{
+    if (scldpc::check_params(p)) return 0;
+    const int S = p->cns_pos * p->dc;
+    return p->dv == 4 && p->dc == 8 && (S & 3) == 0 && S <= 4096 && p->vns_pos * p->dv == S && scldpc::n_of(p) < 65535;
+}
+
+extern "C" int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                                int32_t ntrials, double eps, int32_t ndoped,
+                                                const int32_t *doped_positions, uint16_t *d_vn_adj16,
+                                                uint16_t *d_cn_adj16, uint32_t *d_chan_bits, void *stream)
+{
+    const char *who = "scldpc_sample_philox_device_cn16";
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (!scldpc_sample_philox_cn16_supported(p))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 4096 sockets per position and "
+                                 "fewer than 65535 VNs (got dv=%d dc=%d cns_pos=%d n=%d)", who, p->dv, p->dc, p->cns_pos,
+                                 scldpc::n_of(p));
+    if (ntrials < 0 || (ntrials > 0 && (!d_vn_adj16 || !d_chan_bits)))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
+    if (ndoped < 0 || ndoped > kMaxDoped || (ndoped > 0 && !doped_positions))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: 0 <= ndoped <= %d", who, kMaxDoped);
+    if (!(eps >= 0.0 && eps <= 1.0))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: eps=%g outside [0,1]", who, eps);
+    if (ntrials == 0) return SCLDPC_OK;
+
+    S2Args a{};
+    a.L = p->L; a.cns_pos = p->cns_pos; a.vns_pos = p->vns_pos;
+    a.n = scldpc::n_of(p); a.S = p->cns_pos * p->dc; a.D = p->L + p->dv - 1; a.nw = scldpc::nw_of(p);
+    int lg = 10;                                    // nb = power of two >= max(S, kThreads): the histogram of sampler.hip
+    while ((1 << lg) < a.S) lg++;
+    a.nb = 1 << lg; a.shift = 32 - lg; a.sbits = lg;
+    a.ndoped = ndoped;
+    for (int d = 0; d < ndoped; d++) {
+        if (doped_positions[d] < 0 || doped_positions[d] >= p->L)
+            return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "doped position %d outside [0,%d)", doped_positions[d], p->L);
+        a.doped[d] = doped_positions[d];
+    }
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.trial0 = trial0;
+    {   // erased iff r/RAND_MAX < eps with r = 31-bit draw  ⇔  r < ceil(eps * RAND_MAX)   (BPF:370,1554-1562)
+        const double x = eps * 2147483647.0;
+        double c = (double)(uint64_t)x;
+        if (c < x) c += 1.0;
+        a.thresh = (uint32_t)c;
+    }
+    int off = (a.nb + 3) & ~3;
+    a.off_gpk = off;   off += (a.S + 3) & ~3;
+    a.off_win = off;   off += (2 * a.S + 3) & ~3;           // dv * S uint16
+    a.off_stage = off; off += (a.S / 2 + 3) & ~3;
+    a.off_wsum = off;  off += 32 + 2 * kWorkCap;
+    const size_t lds_bytes = 4u * (size_t)off;
+    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
+
+    const int rows = a.nb / kThreads;                       // 1, 2 or 4
+    void (*kern)(const S2Args) = rows == 1 ? sample_philox_v2_kernel<1> : rows == 2 ? sample_philox_v2_kernel<2>
+                                                                                    : sample_philox_v2_kernel<4>;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
+    SCLDPC_HIP_CHECK(hipGetLastError());
+    return SCLDPC_OK;
+}

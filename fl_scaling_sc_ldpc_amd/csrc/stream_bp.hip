@@ -21,6 +21,7 @@
 // (socket>>2, c, stream id), channel of VN position q = counter (t>>2, 2^31 | q, stream id).
 #include "common.h"
 #include "kernel_util.h"
+#include "philox.h"
 
 namespace {
 
@@ -47,18 +48,7 @@ struct Args {
     int32_t *trace;             // optional [nstreams][npos][10]
 };
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+using scldpc_dev::philox4x32_10;
 
 __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos)     // BPF:1589-1612
 {

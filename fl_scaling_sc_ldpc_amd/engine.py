@@ -122,6 +122,52 @@ def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=
     return d_adj, d_ch
 
 
+def cn16_supported(p):
+    """The (4,8) chain with N <= 1024: the second-generation sampler + the 4-bits-per-CN decoder take it."""
+    return bool(lib().scldpc_sample_philox_cn16_supported(C.byref(p))) and bool(lib().scldpc_full_bp_cn16_supported(C.byref(p)))
+
+
+def sample_philox_cn16(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None, want_cn=True):
+    """scldpc_sample_philox_device_cn16: (vn_adj16 int16 [T,n,4], cn_adj16 int16 [T,nk,8] | None, chan int32 [T,nw]);
+    the first and the last are bit for bit sample_philox(..., adj16=True)'s; cn_adj16 holds the VNs of every CN as
+    uint16 bit patterns (0xFFFF: none), in unspecified order."""
+    _require_gpu()
+    if out is None:
+        d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int16, device=device)
+        d_cn = torch.empty((ntrials, p.nk, p.dc), dtype=torch.int16, device=device) if want_cn else None
+        d_ch = torch.empty((ntrials, p.nw), dtype=torch.int32, device=device)
+    else:
+        d_adj, d_cn, d_ch = out
+    darr, dptr = _lib.doped_array(doped)
+    check(lib().scldpc_sample_philox_device_cn16(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size,
+                                                 dptr, d_adj.data_ptr(), d_cn.data_ptr() if d_cn is not None else None,
+                                                 d_ch.data_ptr(), _stream_ptr(d_adj.device)))
+    return d_adj, d_cn, d_ch
+
+
+def cn_adj_from_vn_adj(p, adj16):
+    """Host: the CN -> VN table (uint16 [.., nk, dc] as int16 bit patterns: the VNs of every CN in ascending order,
+    0xFFFF where a chain-end CN has fewer than dc) from the position-local VN -> CN table — for feeding host-sampled
+    codes (glibc replay, fixtures) to full_bp_fixpoint_cn16, and for checking the device table."""
+    a = np.ascontiguousarray(adj16).view(np.uint16).astype(np.int64).reshape(-1, p.n, p.dv)
+    if p.n >= 0xFFFF:
+        raise ValueError("the CN -> VN table holds 16-bit VN indices: n must be below 65535")
+    T = a.shape[0]
+    out = np.full((T, p.nk, p.dc), 0xFFFF, dtype=np.uint16)
+    pos = np.arange(p.n) // p.vns_pos
+    for k in range(T):
+        cn = ((pos[:, None] + np.arange(p.dv)[None, :]) * p.cns_pos + a[k]).ravel()      # CN of every edge, VN-major
+        vn = np.repeat(np.arange(p.n), p.dv)
+        order = np.lexsort((vn, cn))
+        cn_s, vn_s = cn[order], vn[order]
+        start = np.searchsorted(cn_s, np.arange(p.nk))
+        slot = np.arange(cn_s.size) - start[cn_s]
+        if slot.max() >= p.dc:
+            raise ValueError("a CN has more than dc neighbours")
+        out[k, cn_s, slot] = vn_s
+    return out.view(np.int16)
+
+
 def adj16_to_global(p, adj16):
     """Host: uint16 position-local ids [.., n, dv] → the int32 global CN ids of the reference's VNdegree."""
     a = np.ascontiguousarray(adj16).view(np.uint16).astype(np.int32)
@@ -177,6 +223,24 @@ def full_bp_fixpoint(p, d_adj, d_chan, is_term=True, want_erased=False, counters
     fn = lib().scldpc_full_bp_fixpoint_device_adj16 if _is_adj16(d_adj) else lib().scldpc_full_bp_fixpoint_device
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), 1 if is_term else 0, counters.data_ptr(),
              erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    return {"counters": counters, "rows": None, "erased": erased}
+
+
+def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=False, counters=None):
+    """scldpc_full_bp_fixpoint_device_cn16: full_bp_fixpoint's counters from the VN -> CN and CN -> VN tables."""
+    _require_gpu()
+    T = d_adj16.shape[0]
+    assert d_adj16.is_cuda and d_adj16.dtype == torch.int16 and d_adj16.is_contiguous()
+    assert d_cn16.is_cuda and d_cn16.dtype == torch.int16 and d_cn16.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    assert tuple(d_adj16.shape[1:]) == (p.n, p.dv) and tuple(d_cn16.shape) == (T, p.nk, p.dc) and tuple(d_chan.shape) == (T, p.nw)
+    dev = d_adj16.device
+    if counters is None:
+        counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+    erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    check(lib().scldpc_full_bp_fixpoint_device_cn16(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(),
+                                                    1 if is_term else 0, counters.data_ptr(),
+                                                    erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
     return {"counters": counters, "rows": None, "erased": erased}
 
 

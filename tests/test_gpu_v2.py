@@ -1,0 +1,93 @@
+"""Second-generation throughput path (-m gpu): sampler_v2.hip (ranking only where a bucket straddles two CNs, CN -> socket
+table) and full_bp_small.hip (4 bits of LDS per CN) against the first generation, the CPU twin, and the reference's
+fixtures.  Everything through the C-ABI (engine.py is ctypes plumbing)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, require_gpu
+
+pytestmark = pytest.mark.gpu
+
+KEEP = [0, 1, 2, 3, 4, 6, 7]            # every counter except the iteration / barrier-round count
+
+
+@pytest.fixture(scope="module")
+def E():
+    require_gpu()
+    from fl_scaling_sc_ldpc_amd import engine
+    return engine
+
+
+def _check_cn_table(E, p, adj16, cn16):
+    """cn16 [nk, dc]: as a set per CN, exactly the VNs the VN -> CN table attaches to it (0xFFFF where a chain-end CN has
+    fewer than dc) — i.e. the host's inversion of the same table, up to the order within a CN."""
+    c = np.sort(np.ascontiguousarray(cn16).view(np.uint16), axis=1)
+    want = E.cn_adj_from_vn_adj(p, adj16)[0].view(np.uint16)            # ascending VNs, then 0xFFFF
+    assert (c == want).all()
+
+
+@pytest.mark.parametrize("L,N,eps,doped", [(50, 1000, 0.48, ()), (10, 10, 0.48, ()), (20, 100, 0.3, (3, 4)), (7, 66, 0.9, ()),
+                                           (50, 1000, 0.48, (24, 25)), (12, 1024, 0.45, (5,)), (5, 128, 0.0, ()),
+                                           (5, 128, 1.0, (0,)), (16, 512, 0.5, ()), (9, 600, 0.47, ())])
+def test_sampler_v2_equals_first_generation_and_twin(E, oracle, L, N, eps, doped):
+    import torch
+    p = E.make_params(4, 8, L, N)
+    assert E.cn16_supported(p)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    seed, t0, T = 0x123456789ABCDEF, (1 << 33) + 5, 5
+    a1, c1 = E.sample_philox(p, seed, t0, T, eps, doped, adj16=True)
+    a2, cn2, c2 = E.sample_philox_cn16(p, seed, t0, T, eps, doped)
+    a3, _, c3 = E.sample_philox_cn16(p, seed, t0, T, eps, doped, want_cn=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(a1, a3) and torch.equal(c1, c3)
+    A, CN = a2.cpu().numpy(), cn2.cpu().numpy()
+    ta, tch = oracle.sample_philox(po, seed, t0, eps, doped)            # CPU twin (global ids)
+    assert (E.adj16_to_global(p, A[0]) == ta).all()
+    for t in range(2 if N >= 500 else T):
+        _check_cn_table(E, p, A[t], CN[t])
+
+
+@pytest.mark.parametrize("L,N,eps,is_term", [(50, 1000, 0.48, True), (50, 1000, 0.45, True), (50, 1000, 0.49, False),
+                                             (16, 200, 0.47, True), (16, 200, 0.30, True), (9, 24, 0.5, False),
+                                             (12, 1024, 0.46, True), (30, 400, 0.44, False), (10, 10, 0.48, True),
+                                             (6, 16, 0.9, True), (6, 16, 0.05, True)])
+def test_small_decoder_equals_flooding_and_fixpoint_kernels(E, L, N, eps, is_term):
+    """Same trials through full_bp (level-synchronous flooding), full_bp_fixpoint (16-bit CN words) and
+    full_bp_fixpoint_cn16 (4-bit counts + CN -> VN table): identical counters and identical residual patterns."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 96 if N >= 1000 else 192
+    a, cn, ch = E.sample_philox_cn16(p, 77, 1000, T, eps)
+    ref = E.full_bp(p, a, ch, is_term=is_term, want_erased=True)
+    fix = E.full_bp_fixpoint(p, a, ch, is_term=is_term, want_erased=True)
+    sm = E.full_bp_fixpoint_cn16(p, a, cn, ch, is_term=is_term, want_erased=True)
+    torch.cuda.synchronize()
+    r, f, s = (x["counters"].cpu().numpy() for x in (ref, fix, sm))
+    assert (r[:, KEEP] == s[:, KEEP]).all() and (f[:, KEEP] == s[:, KEEP]).all()
+    assert torch.equal(ref["erased"], sm["erased"])
+
+
+@pytest.mark.parametrize("name", golden_names(prefixes=("c2_bpf", "mid_bpf", "tiny_bpf", "ss2_bpf", "mid_bpt", "tiny_bpt")))
+def test_small_decoder_on_reference_fixtures(E, name):
+    """The reference's own graphs and channels (glibc replay on the fixture's seeds), CN -> VN table built on the host:
+    the unlimited-iteration fixtures' counters (incl. the size-2 stopping-set expurgation of the Def_M = 3 ensembles) and
+    residual patterns."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    if g.max_it:
+        pytest.skip("capped fixture: the fixpoint kernels take unlimited iterations only")
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
+    T = min(g.T, 16 if p.n > 10000 else 64)
+    adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])
+    a16 = E.global_to_adj16(p, adj)
+    cn16 = E.cn_adj_from_vn_adj(p, a16)
+    d_a, d_ch = E.to_device(a16, ch)
+    d_cn = torch.from_numpy(cn16).to(d_a.device)
+    out = E.full_bp_fixpoint_cn16(p, d_a, d_cn, d_ch, is_term=bool(m["is_term"]), want_erased=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    assert (c[:, 0] == g["ne"][:T]).all() and (c[:, 1] == g["be"][:T]).all()
+    assert (c[:, 2] == g["ee"][:T]).all() and (c[:, 3] == g["bee"][:T]).all() and (c[:, 7] == g["nch"][:T]).all()
+    if g.has("erased"):
+        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()

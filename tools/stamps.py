@@ -39,5 +39,9 @@ show("full_bp_kernel", ["clear+channel", "build", "release", "wave reductions", 
                         "final+expurgation"])
 out2 = E.full_bp_fixpoint(p, d_adj, d_ch)
 show("full_bp_fixpoint_kernel", ["channel+build", "peeling (rounds + barrier-free phase)", "final+expurgation"])
+a2, cn2, ch2 = E.sample_philox_cn16(p, 1, 0, T, 0.48)
+show("sample_philox_v2_kernel", ["emit(prev)", "keys+histogram", "scan", "classify", "rank+stage+clear", "emit", "channel"])
+out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
+show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
 it = out["counters"][:, 5].float().mean().item()
 print("mean iterations", it)
