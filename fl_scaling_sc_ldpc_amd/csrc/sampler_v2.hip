@@ -74,19 +74,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
     if (tid == 0) wsum[kWaves] = 0;
     __syncthreads();
+    // The keys of position p+1 are drawn (pure VALU) while the few worklist lanes of position p chase their bucket mates
+    // through the LDS: nxt[] carries them across the barrier.
+    uint32_t nxt[4] = {0, 0, 0, 0};
+    if (mine4) philox4x32_10((uint32_t)tid, 0u, t_lo, t_hi, a.seed_lo, a.seed_hi, nxt);
     for (int p = 0; p < a.D; p++) {
         STAMP(0);
-        // ---- keys + bucket histogram
+        // ---- bucket histogram of this position's keys
         uint32_t key[4], slot[4], crowded = 0;
         {
-            uint32_t r[4] = {0, 0, 0, 0};
-            if (mine4) philox4x32_10((uint32_t)tid, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                key[u] = r[u];
+                key[u] = nxt[u];
                 slot[u] = 0;
                 if (mine4) {
-                    const uint32_t b = r[u] >> kshift, sh = (b & 3u) * 4u;
+                    const uint32_t b = key[u] >> kshift, sh = (b & 3u) * 4u;
                     slot[u] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFu;
                     crowded = max(crowded, slot[u]);
                 }
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 wp[sck] = (uint16_t)(r >> DC_SHIFT);
             }
         }
+        if (mine4 && p + 1 < a.D) philox4x32_10((uint32_t)tid, (uint32_t)(p + 1), t_lo, t_hi, a.seed_lo, a.seed_hi, nxt);
         __syncthreads();
         if (tid == 0) wsum[kWaves] = 0;                                  // read again only after the next two barriers
         STAMP(4);

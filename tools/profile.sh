@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc WRITE_SIZE  (own pass)       → HBM write bytes per dispatch
 # Raw CSVs land in gpurun_out/prof_$TAG/; tools/summarize_prof.py condenses them into profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -17,4 +17,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROO
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
 echo "write done"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_rdreq -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_rdreq.log 2>&1 || echo "rdreq pass failed"
+echo "rdreq done"
 find $OUT -name "*.csv" | head -20
