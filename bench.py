@@ -90,14 +90,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="trials per GPU per step")
+    ap.add_argument("--batch", type=int, default=32768, help="trials per GPU per step (27 GB of tables per buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flooding", action="store_true",
                     help="decode with the level-synchronous kernel (one barrier round per flooding iteration, reports the "
                          "iteration count) instead of the fixpoint kernel (same outputs, no iteration count)")
     ap.add_argument("--overlap", action="store_true",
-                    help="two streams: the sampler of step k+1 beside the decoder of step k (default: one stream)")
-    ap.add_argument("--no-overlap", action="store_true", help="(default) one stream: sample, then decode, then accumulate")
+                    help="(default) two streams, two buffers: the sampler of step k+1 fills the tail of the decoder of step k")
+    ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
     ap.add_argument("--adj32", action="store_true", help="int32 global-id adjacency instead of the compact uint16 one")
     ap.add_argument("--gen1", action="store_true",
                     help="first-generation kernels: sampler that ranks every key + fixpoint decoder on 16-bit CN words "
@@ -121,9 +121,10 @@ def main():
     from fl_scaling_sc_ldpc_amd import engine as E
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch
-    # One stream by default.  --overlap: two (adjacency, channel, counters) buffers and two streams, the sampler of step
-    # k+1 beside the decoder of step k — worth +1 % now that each kernel fills a CU's wave slots on its own.
-    a.no_overlap = not a.overlap
+    # Two streams by default: two (tables, channel, counters) buffers, the sampler of step k+1 beside the decoder of step k.
+    # The decoder's trials differ 10x in length (a successful decode walks the whole chain), so its launch ends in a
+    # tail of long trials on a mostly empty chip: the next step's sampler fills it (+3-4 %).
+    a.overlap = not a.no_overlap
     nbuf = 1 if a.no_overlap else 2
     gen2 = not (a.gen1 or a.flooding or a.adj32)
     if gen2 and not E.cn16_supported(p):

@@ -26,6 +26,7 @@ constexpr int kBlock = 64;
 struct Args {
     int dv, vns_pos, cns_pos, n, ncn, total_size, steps, nw, nd1;     // nd1 = 64-bit words of the degree-1 bitmap
     int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
+    int bshift;                     // a rank-select block covers 2^bshift CNs (64 * 2^(bshift-12) bitmap words)
     uint32_t magic_v, seed_lo, seed_hi;
     unsigned long long trial0;
     int off_d1, off_blk, off_mt, off_sc;   // LDS offsets (32-bit words) behind the CN words
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         const int c = base + tid;
         const bool one = c < ts && (ldw(c) >> kCntShift) == 1u;
         const unsigned long long m = __ballot(one);
-        if (lane == 0 && c < ts) { d1[c >> 6] = m; if (m) atomicAdd(&blk[c >> 12], __popcll(m)); }
+        if (lane == 0 && c < ts) { d1[c >> 6] = m; if (m) atomicAdd(&blk[c >> a.bshift], __popcll(m)); }
         n1_local += one;
     }
     {
@@ -160,21 +161,31 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
         const uint32_t binc = wave_inclusive_scan(bc);
         const int B0 = __ffsll((long long)__ballot(binc > x)) - 1;
         uint32_t r = x - (uint32_t)__builtin_amdgcn_readlane((int)(binc - bc), B0);
-        const int widx = B0 * 64 + lane;
-        unsigned long long word = 0ull;
-        if (widx < a.nd1) {
-            if constexpr (D1G) word = __hip_atomic_load(&d1[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else               word = d1[widx];
+        // block B0 = 64 * kw bitmap words; lane l holds its words l*kw .. l*kw + kw - 1 (kw = 1 up to 262144 pickable CNs)
+        const int kw = 1 << (a.bshift - 12);
+        unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+        uint32_t wc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int widx = (B0 * 64 + lane) * kw + q;
+            if (q < kw && widx < a.nd1) {
+                if constexpr (D1G) word[q] = __hip_atomic_load(&d1[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else               word[q] = d1[widx];
+            }
+            wc += (uint32_t)__popcll(word[q]);
         }
-        const uint32_t wc = (uint32_t)__popcll(word);
         const uint32_t winc = wave_inclusive_scan(wc);
         const int W0 = __ffsll((long long)__ballot(winc > r)) - 1;
         r -= (uint32_t)__builtin_amdgcn_readlane((int)(winc - wc), W0);
         int m = -1;
         if (lane == W0) {
-            unsigned long long w = word;
+            int q = 0;
+            unsigned long long w = word[0];
+#pragma unroll
+            for (int qq = 1; qq < 4; qq++)                              // the word of this lane that holds the r-th set bit
+                if (q == qq - 1 && r >= (uint32_t)__popcll(w)) { r -= (uint32_t)__popcll(w); w = word[qq]; q = qq; }
             while (r--) w &= w - 1;
-            m = widx * 64 + (__ffsll((long long)w) - 1);
+            m = ((B0 * 64 + lane) * kw + q) * 64 + (__ffsll((long long)w) - 1);
         }
         m = __builtin_amdgcn_readlane(m, W0);
         // ---- remove its single VN from all its CNs (PD:769-777) ------------------------------------
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
                 plus = nc == 1u;                        // became 1
                 if (plus || minus) {
                     atomicXor(&d1[c >> 6], 1ull << (c & 63));
-                    atomicAdd(&blk[c >> 12], plus ? 1 : -1);
+                    atomicAdd(&blk[c >> a.bshift], plus ? 1 : -1);
                 }
             }
         }
@@ -245,8 +256,11 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
         if (((x0 * a.magic_v) >> 32) != (uint64_t)q || ((x1 * a.magic_v) >> 32) != x1 / (uint64_t)p->vns_pos)
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: reciprocal division inexact");
     }
-    if (a.nd1 > 4096)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: more than 262144 pickable CNs");
+    // two-level rank-select over the degree-1 bitmap: 64 blocks of 64 * kw words, kw = 1, 2 or 4 words per lane
+    a.bshift = 12;
+    while (a.bshift < 14 && a.nd1 > (64 << (a.bshift - 6))) a.bshift++;
+    if (a.nd1 > (64 << (a.bshift - 6)))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: more than 1048576 pickable CNs");
     // One wave steps one trial through a chain of dependent picks, so throughput = trials in flight.  A workgroup is one
     // wave (up to 32 per CU); what it keeps in LDS decides how many fit: the CN words go to the workspace unless the
     // LDS-resident layout already allows 16 workgroups per CU, and so does the degree-1 bitmap when it is the next obstacle.

@@ -24,6 +24,7 @@ protograph-based chain (flag P, sc_ldpc_protograph.py) and the uncoupled (l,r) e
 indices mod L there (PD:204-205), which is not an ensemble.
 """
 import ast
+import os
 import pickle
 import random
 import sys
@@ -105,6 +106,28 @@ def _sample_numpy(e, l, r, L, M, doping_points, is_protograph, is_tail_biting):
     return tr, gen_erasures(e, L, M, doping_points)
 
 
+def _dist():
+    """(torch.distributed | None, rank, world) — one process per GPU (see bp_decoding.py)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def _device(device):
+    """Default device: this rank's GPU (LOCAL_RANK), as torch.distributed.run sets it."""
+    return device if device is not None else "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _split(total, world):
+    """Contiguous, even shares of `total` trials: offsets [world + 1]."""
+    base, rem = divmod(total, world)
+    offs = [0]
+    for r in range(world):
+        offs.append(offs[-1] + base + (1 if r < rem else 0))
+    return offs
+
+
 def _check_flags(is_protograph, is_tail_biting=False):
     if is_protograph and is_tail_biting:
         raise NotImplementedError("protograph + tail-biting: the reference reduces CN indices mod L (PD:204-205), "
@@ -140,9 +163,16 @@ class _Geometry:
 
 
 def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is_tail_biting, num_repeats=int(1e5),
-                     max_fuckups=2000, doping_points=[], rng="numpy", seed=0, batch=None, device="cuda:0"):
-    """Error-rate Monte-Carlo of the sweep peeling decoder (PD:591-701); returns the reference's 13-tuple."""
+                     max_fuckups=2000, doping_points=[], rng="numpy", seed=0, batch=None, device=None):
+    """Error-rate Monte-Carlo of the sweep peeling decoder (PD:591-701); returns the reference's 13-tuple.
+    rng="philox" under torch.distributed: every round of world*batch trials is split evenly over the ranks, the
+    per-trial result rows (32 B each) are all-gathered and every rank runs the same ordered accumulation, so the stop
+    rule (max_fuckups, PD:698) cuts at the same trial and every rank returns the same tuple as a single rank would."""
     _check_flags(is_protograph, is_tail_biting)
+    device = _device(device)
+    dist, rank, world = _dist()
+    if rng == "numpy" and world > 1:
+        raise ValueError("rng='numpy' replays the reference's one sequential stream: single rank only")
     g = _Geometry(l, r, L, M, is_terminated, is_bounded, doping_points)
     p = g.params
     if batch is None:
@@ -152,7 +182,9 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
     total_blocks_generated = total_blocks_failed_exp = 0
     done = 0
     while done < num_repeats:
-        nb = min(batch, num_repeats - done)
+        nb = min(batch * world, num_repeats - done)         # trials of this round (all ranks)
+        offs = _split(nb, world)
+        lo, mine = offs[rank], offs[rank + 1] - offs[rank]
         states = None
         if rng == "numpy":
             adj = np.empty((nb, p.n, l), dtype=np.int32)
@@ -167,11 +199,19 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
             if isinstance(doping_points, dict):
                 raise NotImplementedError("soft doping needs the host sampler (rng='numpy')")
             ens = "protograph" if is_protograph else "tail_biting" if is_tail_biting else "olmos"
-            d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, _doped_positions(doping_points), device=device,
+            d_adj, d_ch = E.sample_philox(p, seed, done + lo, mine, e, _doped_positions(doping_points), device=device,
                                           adj16=(ens == "olmos"), ensemble=ens)
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
-        out = E.peel_sweep(p, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"].cpu().numpy()
+        d_out = E.peel_sweep(p, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"]
+        if world > 1:
+            m = max(offs[r + 1] - offs[r] for r in range(world))
+            pad = torch.zeros((m, d_out.shape[1]), dtype=d_out.dtype, device=d_out.device)
+            pad[:mine] = d_out
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            d_out = torch.cat([parts[r][:offs[r + 1] - offs[r]] for r in range(world)], dim=0)
+        out = d_out.cpu().numpy()
         # ordered accumulation with the reference's stop rule (PD:668-699)
         used = nb
         for t in range(nb):
@@ -200,13 +240,20 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
 
 
 def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_protograph, num_repeats=None,
-                                  doping_points=[], rng="numpy", seed=0, batch=None, device="cuda:0",
+                                  doping_points=[], rng="numpy", seed=0, batch=None, device=None,
                                   want_moments=False):
     """Random-pick peeling with the degree-1-CN trajectory (PD:705-789): returns (None, r1, plrs) with
     r1 int64 [num_repeats, num_pd_steps+1] and plrs float64 [num_repeats].  want_moments=True (philox mode) returns
-    (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories."""
+    (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories.
+    rng="philox" under torch.distributed: rank r runs a contiguous share of the trials (global trial indices, so the
+    draws do not depend on the sharding); one all-reduce sums the moment vectors (24 B per step) and fills in plrs —
+    and the r1 rows when they are asked for — so every rank returns what a single rank would."""
     if not num_repeats:
         num_repeats = 100
+    device = _device(device)
+    dist, rank, world = _dist()
+    if rng == "numpy" and world > 1:
+        raise ValueError("rng='numpy' replays the reference's one sequential stream: single rank only")
     if isinstance(doping_points, dict):
         raise NotImplementedError("simulate_peeling_decoder_ldpc takes hard doping points only (PD:747)")
     cpp = int(l_deg / r_deg * M)
@@ -241,27 +288,39 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
         # one wave steps one trial: the kernel wants ~8192 trials in flight; stay below ~16 GB of device buffers
         per_trial = L * M * l_deg * 4 + (0 if want_moments else 4 * (num_pd_steps + 1))
         batch = max(256, min(8192, int(16e9 // per_trial)))
-    for done in range(0, num_repeats, batch):
-        nb = min(batch, num_repeats - done)
+    offs = _split(num_repeats, world)
+    if want_moments:
+        moments = torch.zeros((3, num_pd_steps + 1), dtype=torch.int64, device=device)
+    for done in range(offs[rank], offs[rank + 1], batch):
+        nb = min(batch, offs[rank + 1] - done)
         d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device,
                                       adj16=not is_protograph, ensemble="protograph" if is_protograph else "olmos")
-        if want_moments and moments is None:
-            moments = torch.zeros((3, num_pd_steps + 1), dtype=torch.int64, device=device)
         res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done,
                           want_r1=not want_moments, moments=moments)
         o = res["out"].cpu().numpy()
         plrs[done:done + nb] = (o[:, 0] - o[:, 1]) / total_generated
         if not want_moments:
             r1_all[done:done + nb] = res["r1"].cpu().numpy()
+    if world > 1:                                           # shares are disjoint: a sum puts them together
+        t_plr = torch.from_numpy(plrs).to(device)
+        dist.all_reduce(t_plr)
+        plrs = t_plr.cpu().numpy()
+        if want_moments:
+            dist.all_reduce(moments)
+        else:
+            t_r1 = torch.from_numpy(r1_all).to(device)
+            dist.all_reduce(t_r1)
+            r1_all = t_r1.cpu().numpy()
     return None, (moments.cpu().numpy() if want_moments else r1_all), plrs
 
 
-def simulate_peeling_decoder_ldpc_uncoupled(e, l_deg, r_deg, M, num_repeats=None, device="cuda:0"):
+def simulate_peeling_decoder_ldpc_uncoupled(e, l_deg, r_deg, M, num_repeats=None, device=None):
     """Random-pick peeling on the uncoupled (l,r) ensemble (PD:793-869): returns (None, r1, plrs, num_vns_lst).
     Graphs and channels come from the global numpy stream (ldpc.gen_slots with its repeat rejection, PD:134-135), the
     picks from the global `random` stream; both are left where the reference leaves them."""
     if not num_repeats:
         num_repeats = 100
+    device = _device(device)
     cpp = int(l_deg / r_deg * M)
     num_pd_steps = int(M * (e + 0.1))                                      # PD:804
     # one CN position of cpp CNs; the device kernels only need CN ids < total_size = cpp (global-id adjacency)
@@ -396,7 +455,7 @@ def main_simulate_variance(argv=None, **kw):
                                                       want_moments=True, **dict(kw, seed=kw.get("seed", 0) + i))
         else:
             _, r1s, _ = simulate_peeling_decoder_ldpc(e, l, r, L, M, is_terminated, is_protograph, num_runs_batch, **kw)
-            mom = E.r1_moments(torch.from_numpy(r1s.astype(np.int32)).to(kw.get("device", "cuda:0"))).cpu().numpy()
+            mom = E.r1_moments(torch.from_numpy(r1s.astype(np.int32)).to(_device(kw.get("device")))).cpu().numpy()
         ss, cn = nu_chunk_from_moments(mom, r1s_theory, M)
         ssquares = ss if ssquares is None else ssquares + ss
         counts = cn if counts is None else counts + cn

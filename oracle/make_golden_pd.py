@@ -226,7 +226,29 @@ def main2():
         print("pd_" + name, len(r1s), flush=True)
 
 
+# BASELINE config 3 at full size — (4,8), L = 50, N = 10000, 290 000 peeling steps (PD:721), the notebook's trajectory
+# ensemble (PD:1213-1239) — one trial per file (minutes each in the reference): (name, e, is_terminated, seed)
+C3_CASES = [("c3_NT", 0.48, False, 700), ("c3_T", 0.46, True, 701)]
+
+
+def main3():
+    import time
+    for name, e, term, s in C3_CASES:
+        t0 = time.time()
+        np.random.seed(s); random.seed(s)
+        _, r1, plr = pd.simulate_peeling_decoder_ldpc(e, 4, 8, 50, 10000, term, False, 1, [])
+        after = (float(np.random.rand()), random.random())               # where both streams stand afterwards
+        np.savez_compressed(os.path.join(GOLDEN, f"pd_trbig_{name}.npz"), seed=np.array([s]), r1=r1.astype(np.int32),
+                            plr=plr, after=np.array(after),
+                            meta=meta(kind="simulate_peeling_decoder_ldpc", name=name, l=4, r=8, L=50, M=10000, e=e,
+                                      is_terminated=term, doping=[]))
+        print("pd_trbig_" + name, r1.shape, "%.0f s" % (time.time() - t0), flush=True)
+
+
 if __name__ == "__main__":
+    if "--c3" in sys.argv:
+        main3()
+        sys.exit(0)
     if "--new-only" not in sys.argv:
         main()
     main2()

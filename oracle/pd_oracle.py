@@ -251,6 +251,29 @@ def random_pick_trial(tr, mask, l, r, L, M, e, is_terminated, rng, num_doping_po
     return r1, (total_generated - total_recovered) / total_generated
 
 
+def random_pick_trial_philox_fast(tr, mask, l, r, L, M, e, is_terminated, seed, trial, num_doping_points=0):
+    """random_pick_trial(..., PhiloxPickStream(seed, trial)) in O(steps log ncn) (oracle/scldpc_oracle.c,
+    orc_random_pick_philox): what a full-size check (N = 10000, 290 000 steps) needs.  Same returns."""
+    import ctypes as C
+    from oracle import oracle as O
+    cpp = int(l / r * M)
+    num_positions = L + l - 1 if is_terminated else L
+    total_size = cpp * num_positions
+    num_pd_steps = int(M * num_positions * (e + 0.1))                    # PD:721
+    tr32 = np.ascontiguousarray(tr, dtype=np.int32)
+    m8 = np.ascontiguousarray(mask, dtype=np.uint8)
+    ncn = int(tr32.max()) + 1
+    r1 = np.zeros(num_pd_steps + 1, dtype=np.int64)
+    fn = O.lib().orc_random_pick_philox
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+    picked = fn(tr32.ctypes.data, m8.ctypes.data, tr32.shape[0], l, ncn, min(total_size, ncn), num_pd_steps,
+                int(seed), int(trial), r1.ctypes.data)
+    total_generated = (L - num_doping_points) * M                         # PD:747
+    total_recovered = total_generated - int(m8.sum()) + int(picked)       # PD:753, 771
+    return r1, (total_generated - total_recovered) / total_generated
+
+
 def simulate_peeling_decoder_ldpc(seed, e, l, r, L, M, is_terminated, num_repeats=1, doping_points=(),
                                   is_protograph=False):
     """simulate_peeling_decoder_ldpc (PD:705-789) after `np.random.seed(seed); random.seed(seed)`."""

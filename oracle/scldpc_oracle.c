@@ -552,3 +552,72 @@ void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, doubl
 {
     orc_sample_philox_ens(p, 0, seed, trial, eps, ndoped, doped, vn_adj, chan_bits);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Random-pick peeling with the degree-1 trajectory — one trial of simulate_peeling_decoder_ldpc */
+/* (PD:740-785, pick_random_deg_1_cn PD:1022-1026) on the device's Philox pick stream            */
+/* (csrc/peel_pick.hip, rng_mode 1), in O(steps * log ncn): the reference and the numpy model    */
+/* (pd_oracle.random_pick_trial) rescan all CN degrees at every step, which takes minutes at the */
+/* notebook's size (N = 10000, 290 000 steps); here the degree-1 CNs sit in a Fenwick tree and   */
+/* the x-th of them in ascending order is found by descent.  tests/test_pd_oracle.py checks it   */
+/* against the numpy model on the same stream.                                                   */
+/* draw i of trial t = word (i & 3) of philox4x32_10(counter = (i >> 2, 0x90000000, t_lo, t_hi), */
+/* key = seed); getrandbits(k) = word >> (32 - k); _randbelow(n) redraws while the value >= n.   */
+/* ------------------------------------------------------------------------------------------ */
+static void fen_add(int32_t *f, int size, int i, int d) { for (i++; i <= size; i += i & -i) f[i] += d; }
+static int fen_select(const int32_t *f, int size, int lg, int k)      /* index of the k-th (0-based) unit */
+{
+    int pos = 0;
+    for (int step = 1 << lg; step; step >>= 1)
+        if (pos + step <= size && f[pos + step] <= k) { pos += step; k -= f[pos]; }
+    return pos;
+}
+
+/* tr: int32 [n][l] global CN ids; mask[n]: 1 = erased.  r1_out: int64 [num_steps + 1].  Returns #VNs recovered by picks. */
+int64_t orc_random_pick_philox(const int32_t *tr, const uint8_t *mask, int n, int l, int ncn, int total_size,
+                               int num_steps, uint64_t seed, uint64_t trial, int64_t *r1_out)
+{
+    int32_t *deg = (int32_t *)calloc((size_t)ncn, sizeof(int32_t));
+    int64_t *idsum = (int64_t *)calloc((size_t)ncn, sizeof(int64_t));
+    int32_t *fen = (int32_t *)calloc((size_t)total_size + 1, sizeof(int32_t));
+    int lg = 0;
+    while ((2 << lg) <= total_size) lg++;
+    for (int j = 0; j < n; j++)
+        if (mask[j])
+            for (int d = 0; d < l; d++) { deg[tr[(size_t)j * l + d]]++; idsum[tr[(size_t)j * l + d]] += j; }
+    int64_t n1 = 0, picked = 0;
+    for (int c = 0; c < total_size; c++)
+        if (deg[c] == 1) { fen_add(fen, total_size, c, 1); n1++; }
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t draw = 0, buf[4] = {0, 0, 0, 0};
+    r1_out[0] = n1;
+    for (int s = 0; s < num_steps; s++) {
+        if (n1 == 0) { r1_out[s + 1] = r1_out[s]; continue; }                    /* PD:765-767: nothing is drawn */
+        int k = 0;
+        while ((n1 >> k) != 0) k++;                                              /* n1.bit_length() */
+        uint32_t x;
+        do {
+            if ((draw & 3u) == 0) {
+                uint32_t ctr[4] = {draw >> 2, 0x90000000u, (uint32_t)trial, (uint32_t)(trial >> 32)};
+                orc_philox4x32_10(ctr, key, buf);
+            }
+            x = buf[draw & 3u] >> (32 - k);
+            draw++;
+        } while ((int64_t)x >= n1);
+        const int m = fen_select(fen, total_size, lg, (int)x);
+        const int j = (int)idsum[m];
+        picked++;
+        for (int d = 0; d < l; d++) {
+            const int c = tr[(size_t)j * l + d];
+            idsum[c] -= j;
+            deg[c]--;
+            if (c < total_size) {
+                if (deg[c] == 1) { fen_add(fen, total_size, c, 1); n1++; }
+                else if (deg[c] == 0) { fen_add(fen, total_size, c, -1); n1--; }
+            }
+        }
+        r1_out[s + 1] = n1;
+    }
+    free(deg); free(idsum); free(fen);
+    return picked;
+}

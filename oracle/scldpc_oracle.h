@@ -116,6 +116,10 @@ void orc_sample_philox_ens(const orc_params *p, int ensemble, uint64_t seed, uin
 void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, double eps,
                        int ndoped, const int *doped, int32_t *vn_adj, uint32_t *chan_bits);
 
+/* One trial of simulate_peeling_decoder_ldpc (PD:740-785) on the device's Philox pick stream, O(steps log ncn). */
+int64_t orc_random_pick_philox(const int32_t *tr, const uint8_t *mask, int n, int l, int ncn, int total_size,
+                               int num_steps, uint64_t seed, uint64_t trial, int64_t *r1_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,3 +155,83 @@ def test_streaming_driver_two_ranks_equal_one_rank(tmp_path):
     assert f1 == f2 and len(f1) == 1
     a, b = open(os.path.join(d2, f2[0])).read(), open(os.path.join(d1, f1[0])).read()
     assert a == b and len(a.splitlines()) == 4          # header + one row per eps point
+
+
+# ---- the Python peeling mirror: trial ranges per rank, one all-reduce / all-gather (device work faked) --------------------
+def _fake_engine(PD):
+    """Replace the three device calls of peeling_decoding.py by pure functions of the GLOBAL trial index."""
+    import types
+
+    def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cpu", out=None, adj16=False, ensemble="olmos"):
+        ids = torch.arange(trial0, trial0 + ntrials, dtype=torch.int64)
+        return ids, ids
+
+    def peel_sweep(p, d_adj, d_chan, total_size, sweep_start=0, lost_lo=0, lost_hi=None, want_lost=False):
+        h = (d_adj * 2654435761 + 12345) & 0xFFFFFFFF
+        fail = (h >> 7) % 3 != 0
+        lost = torch.where(fail, 1 + h % 97, torch.zeros_like(h))
+        out = torch.zeros((d_adj.shape[0], 8), dtype=torch.int32)
+        out[:, 0] = lost.to(torch.int32)
+        out[:, 1] = torch.where(lost > 2, lost, torch.zeros_like(lost)).to(torch.int32)
+        out[:, 2] = (lost > 2).to(torch.int32) * (1 + (h % 5)).to(torch.int32)
+        return {"out": out, "lost": None}
+
+    def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, trial0=0, want_r1=True, moments=None):
+        T = d_adj.shape[0]
+        steps = torch.arange(num_steps + 1, dtype=torch.int64)[None, :]
+        r1 = ((d_adj[:, None] * 7919 + steps * 104729) % 23) * ((steps + d_adj[:, None]) % 5 != 0)
+        out = torch.zeros((T, 4), dtype=torch.int32)
+        out[:, 0] = (50 + d_adj % 11).to(torch.int32)
+        out[:, 1] = (d_adj % 7).to(torch.int32)
+        if moments is not None:
+            moments[0] += (r1 != 0).sum(0)
+            moments[1] += r1.sum(0)
+            moments[2] += (r1 * r1).sum(0)
+        return {"out": out, "r1": r1.to(torch.int32) if want_r1 else None, "moments": moments}
+
+    PD.E = types.SimpleNamespace(sample_philox=sample_philox, peel_sweep=peel_sweep, peel_pick=peel_pick,
+                                 CodeParams=PD.E.CodeParams)
+
+
+def _pd_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fl_scaling_sc_ldpc_amd import peeling_decoding as PD
+    _fake_engine(PD)
+    out = []
+    for reps, maxf, batch in ((37, 2000, 4), (50, 9, 8), (5, 2000, 64)):
+        t = PD.simulate_sc_ldpc(0.45, 4, 8, 10, 20, True, False, True, False, num_repeats=reps, max_fuckups=maxf,
+                                rng="philox", seed=3, batch=batch, device="cpu")
+        out.append([float(x) for x in t[:8]] + [float(x) for x in t[10:]])
+    _, r1, plrs = PD.simulate_peeling_decoder_ldpc(0.45, 4, 8, 10, 20, False, False, 11, [], rng="philox", seed=3, batch=3,
+                                                   device="cpu")
+    _, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(0.45, 4, 8, 10, 20, False, False, 11, [], rng="philox", seed=3, batch=3,
+                                                     device="cpu", want_moments=True)
+    q.put((rank, out, r1.tolist(), plrs.tolist(), mom.tolist(), plrs2.tolist()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_peeling_mirror_two_ranks_equal_one_rank():
+    """simulate_sc_ldpc (ordered stop rule at max_fuckups, PD:698) and simulate_peeling_decoder_ldpc (r1 rows, plrs, moment
+    vectors) in Philox mode: two ranks return, on BOTH ranks, exactly what one rank returns."""
+    ctx = mp.get_context("spawn")
+    port = 35500 + os.getpid() % 2000
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_pd_worker, args=(r, world, port + world, q)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        got = [q.get(timeout=120) for _ in range(world)]
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        res[world] = {g[0]: g[1:] for g in got}
+    one = res[1][0]
+    assert res[2][0] == one and res[2][1] == one
+    assert one[0][1][5] < 50            # the stop rule cut the second case short

@@ -18,13 +18,27 @@ def big_run():
     p = E.make_params(4, 8, 50, 1000)
     d_adj = torch.empty((BATCH, p.n, 4), dtype=torch.int32, device="cuda")
     d_ch = torch.empty((BATCH, p.nw), dtype=torch.int32, device="cuda")
+    d_a16 = torch.empty((BATCH, p.n, 4), dtype=torch.int16, device="cuda")
+    d_cn16 = torch.empty((BATCH, p.nk, 8), dtype=torch.int16, device="cuda")
+    d_ch2 = torch.empty((BATCH, p.nw), dtype=torch.int32, device="cuda")
     cnts = []
     keep = {}
+    KEEP = [0, 1, 2, 3, 4, 6, 7]                                    # all but the iteration / barrier-round count
     for b in range(T_TOTAL // BATCH):
         E.sample_philox(p, 2024, b * BATCH, BATCH, 0.48, out=(d_adj, d_ch))
         out = E.full_bp(p, d_adj, d_ch, want_erased=(b == 0))
         cnts.append(out["counters"].cpu().numpy())
+        # bench.py's path on the very same trials: second-generation sampler (uint16 tables) + 4-bit-count decoder, and
+        # the first-generation fixpoint kernel on the uint16 adjacency — every counter of every trial must agree with
+        # the level-synchronous flooding kernel on the reference's int32 layout
+        E.sample_philox_cn16(p, 2024, b * BATCH, BATCH, 0.48, out=(d_a16, d_cn16, d_ch2))
+        assert torch.equal(d_ch, d_ch2)
+        small = E.full_bp_fixpoint_cn16(p, d_a16, d_cn16, d_ch2)["counters"].cpu().numpy()
+        fix = E.full_bp_fixpoint(p, d_a16, d_ch2)["counters"].cpu().numpy()
+        assert (small[:, KEEP] == cnts[-1][:, KEEP]).all(), b
+        assert (fix[:, KEEP] == cnts[-1][:, KEEP]).all(), b
         if b == 0:
+            assert (E.adj16_to_global(p, d_a16[::500].cpu().numpy()) == d_adj[::500].cpu().numpy()).all()
             # properties on the first batch
             lim = E.full_bp(p, d_adj, d_ch, max_it=50)["counters"].cpu().numpy()
             again = E.full_bp(p, d_adj, out["erased"])["counters"].cpu().numpy()
@@ -46,6 +60,15 @@ def test_fer_and_plr_match_published_pins(big_run):
     plr = c[:, 0].sum() / (T_TOTAL * p.n)
     assert abs(plr - 0.2102) < 0.004, plr
     assert abs(c[:, 7].mean() / p.n - 0.48) < 2e-4             # channel law
+    # BLER: terminated_fer_plr_bler_sc_ldpc_4_8_50_1000.dat, row eps = 0.48: 26781 failed blocks in 802 failed frames of
+    # 1000 (BLER 0.5356 at that run's FER 0.802) = 33.39 failed blocks per failed frame; a 1000-trial estimate, so the
+    # comparison is on the per-failed-frame mean with its standard error
+    failed = c[:, 0] > 0
+    per_frame = c[failed, 1].astype(np.float64)
+    se = per_frame.std() / np.sqrt(802.0)
+    assert abs(per_frame.mean() - 26781 / 802) < 4.5 * se, (per_frame.mean(), se)
+    bler = c[:, 1].sum() / (p.L * T_TOTAL)
+    assert abs(bler - 0.5356 * failed.mean() / 0.802) < 4.5 * se / p.L, bler
 
 
 def test_size_independent_properties(big_run):

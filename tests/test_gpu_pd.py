@@ -310,3 +310,109 @@ def test_protograph_with_tail_biting_is_refused(PD):
         PD.simulate_sc_ldpc(0.45, 4, 8, 10, 20, True, True, True, True, num_repeats=1)
     with pytest.raises(NameError):                      # the reference's own failure for soft doping there (PD:228)
         PD.simulate_sc_ldpc(0.45, 4, 8, 10, 20, True, True, True, False, num_repeats=1, doping_points={3: 0.5})
+
+
+# ---- BASELINE config 3 at full size: (4,8), L = 50, N = 10000 — 290 000 peeling steps per trial (PD:721) ----------------
+TRBIG = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_trbig_*.npz")))
+
+
+@pytest.mark.parametrize("term,e,seed", [(False, 0.48, 2026), (True, 0.46, 2027)])
+def test_config3_full_size_random_pick_equals_cpu_twin(PD, oracle, term, e, seed):
+    """Non-terminated: 250 000 pickable CNs (CN words AND degree-1 bitmap in the workspace, in-kernel moments);
+    terminated: 265 000 (more than 64 blocks of 4096: two bitmap words per lane in the rank-select).  r1 and plr of
+    every trial against the O(steps log n) CPU twin of the same Philox pick stream (pinned to the numpy model of the
+    reference by tests/test_pd_oracle.py), and the in-kernel moments against the r1 rows of the same batch."""
+    from oracle import pd_oracle as P
+    E = PD.E
+    L, M, T = 50, 10000, 3
+    none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=seed)
+    none, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=seed,
+                                                        want_moments=True, batch=2)
+    assert r1.shape == (T, int(M * (L + 3 if term else L) * (e + 0.1)) + 1)
+    p = E.CodeParams(4, 8, L, M // 2, M)
+    d_adj, d_ch = E.sample_philox(p, seed, 0, T, e, adj16=True)
+    A = E.adj16_to_global(p, d_adj.cpu().numpy())
+    bits = E.unpack_bits(d_ch.cpu().numpy(), p.n).astype(bool)
+    for t in range(T):
+        ref_r1, ref_plr = P.random_pick_trial_philox_fast(A[t], bits[t], 4, 8, L, M, e, term, seed, t)
+        assert (r1[t] == ref_r1).all() and plrs[t] == ref_plr, t
+    assert (plrs2 == plrs).all()
+    r64 = r1.astype(np.int64)
+    assert (mom[0] == (r64 != 0).sum(0)).all() and (mom[1] == r64.sum(0)).all() and (mom[2] == (r64 ** 2).sum(0)).all()
+
+
+@pytest.mark.parametrize("path", TRBIG, ids=[os.path.basename(p)[:-4] for p in TRBIG])
+def test_config3_full_size_trajectory_equals_the_reference(PD, path):
+    """One trial of the REAL reference at the notebook's size (oracle/make_golden_pd.py --c3; minutes there) on identical
+    numpy / `random` seeds: every one of the 290 001 r1 values, plr, and where both streams stand afterwards."""
+    z, m, doping = _load(path)
+    s = int(z["seed"][0])
+    np.random.seed(s); random.seed(s)
+    none, r1, plrs = PD.simulate_peeling_decoder_ldpc(m["e"], m["l"], m["r"], m["L"], m["M"], m["is_terminated"], False, 1, doping)
+    assert none is None and r1.shape == z["r1"].shape
+    assert (r1 == z["r1"]).all() and plrs[0] == z["plr"][0]
+    assert (float(np.random.rand()), random.random()) == tuple(z["after"])
+
+
+# ---- the variance workflow and the trajectory producer end to end (SURVEY.md §8a rows P8, P10) ---------------------------
+VARMAIN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_var_main_*.npz")))
+
+
+@pytest.mark.parametrize("path", VARMAIN, ids=[os.path.basename(p)[:-4] for p in VARMAIN])
+def test_main_simulate_variance_equals_the_reference(PD, path, tmp_path):
+    """simulate_variance.py's argv (PD:1264-1294) on identical numpy / `random` seeds and the same theory pickle: the
+    pickled (ssquares, counts) equal what the REAL reference pickled (oracle/make_golden_var.py) — counts exactly,
+    ssquares to 1e-12 relative (integer moments on the device, then one float expression; the reference nansums squared
+    float differences) — and both streams end where the reference leaves them."""
+    import pickle
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    fth, fout = str(tmp_path / "theory.pkl"), str(tmp_path / "out.pkl")
+    with open(fth, "wb") as f:
+        pickle.dump((z["theory"],), f)
+    np.random.seed(m["seed"]); random.seed(m["seed"])
+    PD.main_simulate_variance([fout] + m["argv"] + [fth])
+    assert (float(np.random.rand()), random.random()) == tuple(z["after"])
+    with open(fout, "rb") as f:
+        ss, cnt = pickle.load(f)                            # our own file
+    assert ss.dtype == np.float64 and cnt.dtype == np.int64 and ss.shape == z["ssquares"].shape
+    assert (cnt == z["counts"]).all() and np.allclose(ss, z["ssquares"], rtol=1e-12, atol=1e-300)
+
+
+def test_main_simulate_variance_philox_mode_and_moments(PD, tmp_path):
+    """Throughput mode (Philox streams, in-kernel moments): the chunk statistics equal calc_nu_chunk (pinned to the
+    reference by tests/test_pd_oracle.py) applied to the r1 rows of the very same trials."""
+    import pickle
+    from oracle import pd_oracle as P
+    L, M, e, runs, batch = 12, 200, 0.47, 6, 3
+    steps = int(M * L * (e + 0.1))
+    th = np.where(np.arange(steps + 1) < int(0.7 * steps), 40.0 * np.exp(-np.arange(steps + 1) / 500.0) + 2.0, 0.0)
+    fth, fout = str(tmp_path / "theory.npy"), str(tmp_path / "out.pkl")
+    np.save(fth, th)
+    ss, cnt = PD.main_simulate_variance([fout, "4", "8", str(L), str(M), repr(e), "N", "U", str(runs), str(batch), fth],
+                                        rng="philox", seed=40)
+    r1s = [PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, False, False, batch, [], rng="philox", seed=40 + i)[1]
+           for i in range(runs // batch)]
+    ref_ss, ref_cnt = P.calc_nu_chunk(np.concatenate(r1s).astype(np.int64), th, M)
+    assert (cnt == ref_cnt).all() and np.allclose(ss, ref_ss, rtol=1e-12, atol=1e-300)
+    with open(fout, "rb") as f:
+        ss2, cnt2 = pickle.load(f)
+    assert (ss2 == ss).all() and (cnt2 == cnt).all()
+
+
+def test_test_sc_ldpc_writes_the_reference_pickle(PD, tmp_path):
+    """`python3 peeling_decoding.py` → test_sc_ldpc (PD:1212-1245): batches of trajectories pickled as (r1, plrs) — r1 int64
+    [num_runs_batch, num_pd_steps + 1], plrs float64 — here at a fixture's size on the fixture's seeds: the arrays equal
+    the REAL reference's two-trial call (pd_tr_mid_NT: multi2_*, oracle/make_golden_pd.py)."""
+    import pickle
+    z, m, doping = _load(os.path.join(GOLDEN_DIR, "pd_tr_mid_NT.npz"))
+    s0 = int(z["seed"][0])
+    np.random.seed(s0); random.seed(s0)
+    PD.test_sc_ldpc(l=m["l"], r=m["r"], L=m["L"], M=m["M"], e=m["e"], is_terminated=m["is_terminated"], num_runs=2,
+                    num_runs_batch=2, out_pattern=str(tmp_path / "r1_{l}_{r}_{L}_{M}_{etag}_{term}_{i}.pkl"))
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["r1_%d_%d_%d_%d_%s_nonterminated_0.pkl" % (m["l"], m["r"], m["L"], m["M"], ("%.3f" % m["e"]).replace(".", "")[:4])]
+    with open(tmp_path / files[0], "rb") as f:
+        r1, plrs = pickle.load(f)                           # our own file
+    assert r1.dtype == np.int64 and plrs.dtype == np.float64
+    assert (r1 == z["multi2_r1"]).all() and (plrs == z["multi2_plr"]).all()

@@ -100,3 +100,40 @@ def test_calc_nu_chunk_matches_definition():
     d = x - th[:40] / 100.0
     ok = x != 0
     assert np.allclose(ss, np.where(ok, d ** 2, 0).sum(0)) and (cnt == ok.sum(0)).all()
+
+
+@pytest.mark.parametrize("L,M,e,term", [(10, 20, 0.45, False), (10, 20, 0.5, True), (12, 40, 0.3, True), (8, 64, 0.62, False),
+                                        (20, 200, 0.47, False)])
+def test_fast_random_pick_twin_equals_the_numpy_model(L, M, e, term):
+    """oracle/scldpc_oracle.c orc_random_pick_philox (Fenwick tree, O(steps log n)) — what the full-size C3 check on the
+    GPU uses — against pd_oracle.random_pick_trial (the literal model pinned to the imported reference) on the device's
+    Philox pick stream, incl. runs that exhaust their degree-1 CNs early and redraws of _randbelow."""
+    from oracle import oracle as O
+    from oracle import pd_oracle as P
+    O.build(with_reference=False)
+    for seed, trial in ((5, 0), (5, 1), (99, 123456789012)):
+        rs = np.random.RandomState(seed + trial % 1000)
+        tr = P.gen_slots(rs, 4, 8, L, M)
+        mask = P.gen_erasures(rs, e, 4, 8, L, M)
+        a = P.random_pick_trial(tr, mask, 4, 8, L, M, e, term, P.PhiloxPickStream(seed, trial))
+        b = P.random_pick_trial_philox_fast(tr, mask, 4, 8, L, M, e, term, seed, trial)
+        assert (a[0] == b[0]).all() and a[1] == b[1], (L, M, seed, trial)
+
+
+VAR = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pd_var_chunk_*.npz")))
+
+
+@pytest.mark.parametrize("path", VAR, ids=[os.path.basename(p)[:-4] for p in VAR])
+def test_calc_nu_chunk_equals_the_reference(path):
+    """SURVEY.md §8a row P8: fixtures written by the REAL fl_scaling.est_scaling_params.calc_nu_chunk (:90-94, :131-138;
+    oracle/make_golden_var.py) pin (i) the oracle's restatement and (ii) the product's host-side reduction from integer
+    moments (count, sum r1, sum r1^2 — what the device accumulates), float tolerance 1e-12 relative."""
+    from oracle import pd_oracle as P
+    from fl_scaling_sc_ldpc_amd import peeling_decoding as PD
+    z = np.load(path)
+    r1s, th, M = z["r1s"], z["theory"], int(z["M"])
+    ss, cnt = P.calc_nu_chunk(r1s, th, M)
+    assert (cnt == z["counts"]).all() and np.allclose(ss, z["ssquares"], rtol=1e-13, atol=0)
+    mom = np.stack([(r1s != 0).sum(0), r1s.sum(0), (r1s ** 2).sum(0)]).astype(np.int64)
+    ss2, cnt2 = PD.nu_chunk_from_moments(mom, th, M)
+    assert (cnt2 == z["counts"]).all() and np.allclose(ss2, z["ssquares"], rtol=1e-12, atol=1e-300)
