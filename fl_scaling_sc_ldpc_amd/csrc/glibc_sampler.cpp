@@ -141,3 +141,53 @@ extern "C" int scldpc_sample_glibc_host(const scldpc_code_params *p, uint32_t se
     if (int rc = scldpc_glibc_state_init(p, seed, state.data())) return rc;
     return scldpc_sample_glibc_next_host(p, state.data(), eps, ndoped, doped_positions, 1, vn_adj, chan_bits);
 }
+
+// main_streaming's draws (BPF:1934-2054, the CIRCULAR build) for the first npos_gen generated positions of ONE stream
+// after `srandom(seed)` and inizio_sim's perm_code reset: initialize_arrays_circular shuffles CN positions 0 .. dv-2
+// (BPF:1808-1813), then generate_stream_pos(g) shuffles CN position g + dv - 1 (fill_interleaver_pos, BPF:1763-1787:
+// Fisher-Yates on perm_code, whose state carries over) and draws the channel of VN position g unless it is doped
+// (generate_channel_doped_circular, BPF:1621-1654; periodic doping, is_position_doped_streaming BPF:1589-1612).
+// Decoding draws nothing, so the whole input stream is a function of (seed, eps, doping) alone.
+//   inter_out uint16 [npos_gen + dv - 1][S]: CN-local id perm_code[i] / dc of socket i of CN position c
+//   chan_out  uint32 [npos_gen][ceil(vns_pos/32)]: bit t of position g = 1 iff VN (g, t) is erased
+extern "C" int scldpc_stream_glibc_inputs_host(const scldpc_code_params *p, uint32_t seed, double eps, int32_t ndoped,
+                                               const int32_t *doped_positions, int32_t npos_gen, uint16_t *inter_out,
+                                               uint32_t *chan_out)
+{
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (npos_gen < 0 || !inter_out || !chan_out || ndoped < 0 || (ndoped > 0 && !doped_positions))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_glibc_inputs_host: null buffer or negative count");
+    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, V = p->vns_pos, wpp = (V + 31) / 32;
+    if (p->cns_pos > 65536)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_glibc_inputs_host: cns_pos > 65536");
+    GlibcRandom g;
+    g.seed(seed);
+    std::vector<int32_t> perm((size_t)S);
+    for (int i = 0; i < S; i++) perm[i] = i;                                 // inizio_sim, BPF:308-311
+    auto shuffle_into = [&](uint16_t *row) {
+        for (int i = 0; i < S; i++) {                                          // BPF:1770-1776
+            const int pick = i + g.next() % (S - i);
+            const int32_t t = perm[i]; perm[i] = perm[pick]; perm[pick] = t;
+        }
+        for (int i = 0; i < S; i++) row[i] = (uint16_t)(perm[i] / dc);         // BPF:1782
+    };
+    auto doped = [&](int pos) {                                                // BPF:1589-1612
+        if (ndoped == 0) return false;
+        const int period = doped_positions[ndoped - 1] + 1, m = pos % period;
+        if (m < doped_positions[0]) return false;
+        for (int d = 0; d < ndoped; d++) if (m == doped_positions[d]) return true;
+        return false;
+    };
+    for (int c = 0; c < dv - 1; c++) shuffle_into(inter_out + (size_t)c * S);
+    memset(chan_out, 0, sizeof(uint32_t) * (size_t)npos_gen * wpp);
+    for (int gpos = 0; gpos < npos_gen; gpos++) {
+        shuffle_into(inter_out + (size_t)(gpos + dv - 1) * S);
+        if (doped(gpos)) continue;                                             // no draws for a doped position
+        uint32_t *row = chan_out + (size_t)gpos * wpp;
+        for (int t = 0; t < V; t++) {
+            const double u = (double)g.next() / 2147483647.0;                 // unif_ch, BPF:360-371
+            if (!(u >= eps)) row[t >> 5] |= 1u << (t & 31);
+        }
+    }
+    return SCLDPC_OK;
+}

@@ -43,6 +43,13 @@ struct Args {
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
     StateLayout lay;
+    // same-input mode (scldpc_stream_run_device_inputs): per-position inputs replayed on the host from the reference's
+    // own glibc stream instead of Philox draws — ext_inter uint16 [nstreams][ext_npos + dv - 1][S] = CN-local id of
+    // every socket of CN position c (fill_interleaver_pos, BPF:1763-1787), ext_chan uint32 [nstreams][ext_npos][wpp] =
+    // erasure bits of VN position g (generate_channel_doped_circular, BPF:1621-1654)
+    const uint16_t *ext_inter;
+    const uint32_t *ext_chan;
+    int ext_npos;
     char *state;
     long long *counters_out;    // [nstreams][10]
     int32_t *trace;             // optional [nstreams][npos][10]
@@ -97,6 +104,13 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
     auto rank_position = [&](long long cpos) {
+        if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
+            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)cpos) * S;
+            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
+            __syncthreads();
+            return;
+        }
         for (int b = tid; b < a.nb; b += kThreads) hist[b] = 0;
         __syncthreads();
         for (int q = tid; q < (S + 3) / 4; q += kThreads) {
@@ -162,7 +176,9 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         int erased_here = 0;
         for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
             uint32_t word = 0;
-            if (!doped) {
+            if (a.ext_chan) {
+                word = a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)g) * wpp + w];     // doped positions: all zero
+            } else if (!doped) {
 #pragma unroll
                 for (int c8 = 0; c8 < 8; c8++) {
                     uint32_t r[4];
@@ -396,9 +412,10 @@ extern "C" int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_
     return (int64_t)lay.total;
 }
 
-extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
-                                        double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
-                                        int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream)
+static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
+                      double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
+                      int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace,
+                      const uint16_t *d_ext_inter, const uint32_t *d_ext_chan, int32_t ext_npos, void *stream)
 {
     if (int rc = check_stream(p, W, "scldpc_stream_run_device")) return rc;
     if (nstreams < 0 || npos < 0 || (nstreams > 0 && !d_state))
@@ -431,6 +448,7 @@ extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nst
     }
     make_state_layout(p, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
+    a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos;
     const int rows = a.nb / kThreads;
     const size_t lds_bytes = 4u * ((size_t)a.nb + 2 * (rows <= 4 ? kQCapTwo : kQCapOne) + 32 + kWaves * kWaves + kMaxL + S_NSCAL);
     void (*kern)(const Args) = rows == 1 ? stream_bp_kernel_two_per_cu<1> : rows == 2 ? stream_bp_kernel_two_per_cu<2>
@@ -440,4 +458,29 @@ extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nst
     hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
+                                        double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
+                                        int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream)
+{
+    return stream_run(p, nstreams, seed, stream0, eps, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
+                      nullptr, nullptr, 0, stream);
+}
+
+extern "C" int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int32_t nstreams, int32_t W, int32_t ndoped,
+                                               const int32_t *doped_positions, int32_t npos, void *d_state,
+                                               int64_t *d_counters, int32_t *d_trace, const uint16_t *d_inter,
+                                               const uint32_t *d_chan_bits, int32_t inputs_npos, int64_t positions_done,
+                                               void *stream)
+{
+    if (!d_inter || !d_chan_bits || inputs_npos < 0 || positions_done < 0)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device_inputs: null inputs or negative count");
+    // a stream is generated L/2 positions ahead and one more per decoded position (BPF:2001-2012, 2036-2045)
+    if (p && (int64_t)p->L / 2 + positions_done + npos > (int64_t)inputs_npos)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device_inputs: %lld + %d decoded positions need "
+                                 "%lld generated ones, the inputs hold %d", (long long)positions_done, npos,
+                                 (long long)p->L / 2 + positions_done + npos, inputs_npos);
+    return stream_run(p, nstreams, 0, 0, 0.0, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
+                      d_inter, d_chan_bits, inputs_npos, stream);
 }

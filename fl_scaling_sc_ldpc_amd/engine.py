@@ -371,3 +371,40 @@ class Streams:
                                              self.counters.data_ptr(), tr.data_ptr() if tr is not None else None,
                                              _stream_ptr(self.state.device)))
         return self.counters, tr
+
+
+def stream_glibc_inputs(p, seed, eps, doped, npos_gen):
+    """Host: main_streaming's draws for the first npos_gen generated positions of one stream after srandom(seed)
+    (scldpc_stream_glibc_inputs_host): (inter uint16 [npos_gen + dv - 1, S], chan uint32 [npos_gen, wpp])."""
+    S, wpp = p.cns_pos * p.dc, (p.vns_pos + 31) // 32
+    inter = np.empty((npos_gen + p.dv - 1, S), dtype=np.uint16)
+    chan = np.empty((npos_gen, wpp), dtype=np.uint32)
+    darr, dptr = _lib.doped_array(doped)
+    check(lib().scldpc_stream_glibc_inputs_host(C.byref(p), int(seed) & 0xFFFFFFFF, float(eps), darr.size, dptr, int(npos_gen),
+                                                inter.ctypes.data, chan.ctypes.data))
+    return inter, chan
+
+
+class InputStreams(Streams):
+    """Streams decoded from given per-position inputs (same-input mode): inter [nstreams, G + dv - 1, S] uint16 and
+    chan [nstreams, G, wpp] uint32 as stream_glibc_inputs produces them, G = positions generated."""
+
+    def __init__(self, p, inter, chan, W, doped=(), device="cuda:0"):
+        inter, chan = np.ascontiguousarray(inter, dtype=np.uint16), np.ascontiguousarray(chan, dtype=np.uint32)
+        super().__init__(p, inter.shape[0], 0, 0.0, W, doped, device=device)
+        self.G = chan.shape[1]
+        assert inter.shape[1] == self.G + p.dv - 1 and inter.shape[2] == p.cns_pos * p.dc
+        self.d_inter = torch.from_numpy(inter.view(np.int16)).to(device)
+        self.d_chan = torch.from_numpy(chan.view(np.int32)).to(device)
+        self.done = 0
+
+    def run(self, npos, trace=False):
+        tr = torch.empty((self.n, npos, 10), dtype=torch.int32, device=self.state.device) if trace else None
+        darr, dptr = _lib.doped_array(self.doped)
+        check(lib().scldpc_stream_run_device_inputs(C.byref(self.p), self.n, int(self.W), darr.size, dptr, int(npos),
+                                                    self.state.data_ptr(), self.counters.data_ptr(),
+                                                    tr.data_ptr() if tr is not None else None, self.d_inter.data_ptr(),
+                                                    self.d_chan.data_ptr(), int(self.G), int(self.done),
+                                                    _stream_ptr(self.state.device)))
+        self.done += npos
+        return self.counters, tr

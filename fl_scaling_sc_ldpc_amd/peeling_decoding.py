@@ -352,11 +352,18 @@ def simulate_peeling_decoder_ldpc_uncoupled(e, l_deg, r_deg, M, num_repeats=None
 def nu_chunk_from_moments(moments, r1s_theory, M):
     """calc_nu_chunk from the integer moments (cnt, Σr1, Σr1²) of a batch: ssquares[s] = Σ_{r1≠0} (r1/M − θ/M)²,
     counts[s] = cnt[s], over the support of the theory curve.  Equal to the reference's nansum up to float rounding
-    (relative 1e-12; the reference sums squared float differences, this sums integers first)."""
+    (relative 1e-12; the reference sums squared float differences, this sums integers first).  θ is split into its
+    nearest integer k and a fraction f: Σ(r1−θ)² = Σ(r1−k)² − 2f·Σ(r1−k) + cnt·f² with the first two sums exact in
+    integers, so nothing cancels when the trajectories sit on the theory curve (s2 − 2θ·s1 + cnt·θ² loses five digits
+    there)."""
     last = int(np.max(np.where(r1s_theory > 0))) + 1
     th = r1s_theory[r1s_theory > 0].astype(np.float64)
-    cnt, s1, s2 = (moments[k][:last][:r1s_theory.shape[0]].astype(np.float64) for k in range(3))
-    return (s2 - 2.0 * th * s1 + cnt * th * th) / (M * M), moments[0][:last][:r1s_theory.shape[0]].astype(np.int64)
+    cnt, s1, s2 = (np.asarray(moments[k])[:last][:r1s_theory.shape[0]].astype(np.int64) for k in range(3))
+    k = np.rint(th).astype(np.int64)
+    f = th - k
+    a = s2 - 2 * k * s1 + cnt * k * k                                       # Σ (r1 − k)²   exact
+    b = s1 - cnt * k                                                        # Σ (r1 − k)    exact
+    return (a.astype(np.float64) - 2.0 * f * b + cnt * f * f) / (float(M) * float(M)), cnt
 
 
 class _ArraysOnly(pickle.Unpickler):

@@ -274,6 +274,22 @@ int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nstreams, uint
                              double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
                              int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream);
 
+/* Same-input mode: the streams' inputs are given instead of drawn.  scldpc_stream_glibc_inputs_host replays, for ONE
+ * stream, exactly what main_streaming draws after srandom(seed) (BPF:2059-2062, 1808-1813, 1927-1932): inter_out uint16
+ * [npos_gen + dv - 1][cns_pos*dc] = CN-local id (perm_code[i] / dc, BPF:1782) of socket i of CN position c, chan_out
+ * uint32 [npos_gen][ceil(vns_pos/32)] = erasure bits of VN position g (none at doped positions, BPF:1621-1654).
+ * scldpc_stream_run_device_inputs decodes from such arrays on the device (d_inter [nstreams][inputs_npos + dv - 1][S],
+ * d_chan_bits [nstreams][inputs_npos][wpp], one slice per stream): same state blobs, counters and trace as
+ * scldpc_stream_run_device; positions_done = positions decoded by earlier calls (a stream needs L/2 + positions_done +
+ * npos generated positions).  With the glibc replay the device reproduces a reference run position by position. */
+int scldpc_stream_glibc_inputs_host(const scldpc_code_params *p, uint32_t seed, double eps, int32_t ndoped,
+                                    const int32_t *doped_positions, int32_t npos_gen, uint16_t *inter_out,
+                                    uint32_t *chan_out);
+int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int32_t nstreams, int32_t W, int32_t ndoped,
+                                    const int32_t *doped_positions, int32_t npos, void *d_state, int64_t *d_counters,
+                                    int32_t *d_trace, const uint16_t *d_inter, const uint32_t *d_chan_bits,
+                                    int32_t inputs_npos, int64_t positions_done, void *stream);
+
 /* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
  * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),
  * where k is the first trial at which frame_err reaches stop_frame_err (all trials if it never does

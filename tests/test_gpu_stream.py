@@ -58,3 +58,38 @@ def test_streaming_cli_writes_results_circular_rows(E, tmp_path):
 def test_streaming_rejects_windows_beyond_the_generated_stream(E):
     with pytest.raises(E.ScldpcError, match="L/2"):
         E.Streams(E.make_params(4, 8, 20, 10), 1, 1, 0.4, 9)
+
+
+# ---- same-input mode: the device kernel fed with the reference's own stream ----------------------------------------------
+import glob as _glob
+import os
+import json as _json
+
+_STREAM_GOLDEN = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_*.npz")))
+
+
+@pytest.mark.parametrize("path", _STREAM_GOLDEN, ids=[os.path.basename(p)[:-4] for p in _STREAM_GOLDEN])
+def test_stream_kernel_on_the_reference_stream_equals_the_reference(E, path):
+    """stream_bp.hip fed with main_streaming's own draws — scldpc_stream_glibc_inputs_host replays srandom(seed),
+    fill_interleaver_pos and generate_channel_doped_circular (BPF:1763-1787, 1621-1654) — against the rows the REAL
+    reference (its CIRCULAR build, oracle/make_golden_stream.py) printed position by position: the value returned by
+    decodeBP_SW_circular and all eight counters of results_circular, across buffer wrap-arounds, with and without doping,
+    incl. the N = 1000 fixtures of BASELINE config 5's ensemble family.  Two launches (continuation from the state blob)
+    and two stream slots (the second fed with a different seed's inputs must not disturb the first)."""
+    import torch
+    z = np.load(path)
+    m = _json.loads(str(z["meta"]))
+    p = E.make_params(4, 8, m["L"], 2 * m["Def_M"])
+    P = int(m["P"])
+    G = m["L"] // 2 + P
+    inter, chan = E.stream_glibc_inputs(p, m["seed"], m["eps"], m["doped"], G)
+    inter2, chan2 = E.stream_glibc_inputs(p, m["seed"] + 1, m["eps"], m["doped"], G)
+    st = E.InputStreams(p, np.stack([inter, inter2]), np.stack([chan, chan2]), m["W"], m["doped"])
+    first = P // 3
+    _, tr1 = st.run(first, trace=True)
+    cnt, tr2 = st.run(P - first, trace=True)
+    torch.cuda.synchronize()
+    rows = np.concatenate([tr1[0].cpu().numpy(), tr2[0].cpu().numpy()])
+    assert (rows == z["rows"][:P]).all(), np.argwhere(rows != z["rows"][:P])[:3]
+    c = cnt[0].cpu().numpy()
+    assert c[:8].tolist() == z["rows"][P - 1][2:].tolist() and c[8] == P and c[9] == G
