@@ -34,7 +34,7 @@ EXPORTS = (
     "scldpc_full_bp_fixpoint_device", "scldpc_full_bp_fixpoint_device_adj16",
     "scldpc_sample_philox_cn16_supported", "scldpc_sample_philox_device_cn16",
     "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16",
-    "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs",
+    "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
 )
 
 
@@ -90,25 +90,27 @@ def lib():
     L.scldpc_glibc_state_init.argtypes = [pp, u32, vp]
     L.scldpc_glibc_state_reset_perm.argtypes = [pp, vp]
     L.scldpc_sample_glibc_next_host.argtypes = [pp, vp, dbl, i32, vp, i32, vp, vp]
-    L.scldpc_sample_philox_device.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
+    L.scldpc_workspace_bytes.argtypes = [i32, pp, i32, i32, i32]
+    L.scldpc_workspace_bytes.restype = i64
+    L.scldpc_sample_philox_device.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, u64, vp]
     L.scldpc_sample_philox_ensemble_device.argtypes = [pp, i32, u64, u64, i32, dbl, i32, vp, vp, vp, vp]
-    L.scldpc_full_bp_fixpoint_device.argtypes = [pp, i32, vp, vp, i32, vp, vp, vp]
+    L.scldpc_full_bp_fixpoint_device.argtypes = [pp, i32, vp, vp, i32, vp, vp, vp, u64, vp]
     L.scldpc_full_bp_fixpoint_device_adj16.argtypes = L.scldpc_full_bp_fixpoint_device.argtypes
     L.scldpc_sample_philox_cn16_supported.argtypes = [pp]
     L.scldpc_full_bp_cn16_supported.argtypes = [pp]
     L.scldpc_sample_philox_device_cn16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, vp, vp, vp]
-    L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp]
-    L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, u64, vp]
+    L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes
     L.scldpc_full_bp_device_adj16.argtypes = L.scldpc_full_bp_device.argtypes
     L.scldpc_sw_bp_device_adj16.argtypes = L.scldpc_sw_bp_device.argtypes
-    L.scldpc_peel_sweep_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.scldpc_peel_sweep_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_peel_sweep_device_adj16.argtypes = L.scldpc_peel_sweep_device.argtypes
-    L.scldpc_peel_pick_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, u64, u64, vp, vp, vp, vp]
+    L.scldpc_peel_pick_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, u64, u64, vp, vp, vp, vp, u64, vp]
     L.scldpc_peel_pick_device_adj16.argtypes = L.scldpc_peel_pick_device.argtypes
     L.scldpc_r1_moments_device.argtypes = [i32, i32, vp, vp, vp]
-    L.scldpc_swc_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.scldpc_swc_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_swc_bp_device_adj16.argtypes = L.scldpc_swc_bp_device.argtypes
     L.scldpc_stream_state_bytes.argtypes = [pp, i32]
     L.scldpc_stream_state_bytes.restype = i64

@@ -30,30 +30,32 @@ int check_params(const scldpc_code_params *p)
     return SCLDPC_OK;
 }
 
-static void *g_ws[16][2] = {{nullptr}};
-static size_t g_ws_bytes[16][2] = {{0}};
-
-int workspace(size_t bytes, void **out, int slot)
+int take_scratch(const char *who, const Scratch &s, size_t need, void **out)
 {
-    int dev = 0;
-    SCLDPC_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16 || slot < 0 || slot > 1)
-        return set_error(SCLDPC_ERR_BAD_ARG, "device ordinal %d / workspace slot %d out of range", dev, slot);
-    if (bytes > g_ws_bytes[dev][slot]) {
-        if (g_ws[dev][slot]) {
-            SCLDPC_HIP_CHECK(hipDeviceSynchronize());
-            SCLDPC_HIP_CHECK(hipFree(g_ws[dev][slot]));
-            g_ws[dev][slot] = nullptr; g_ws_bytes[dev][slot] = 0;
-        }
-        const size_t want = bytes + bytes / 4;
-        SCLDPC_HIP_CHECK(hipMalloc(&g_ws[dev][slot], want));
-        g_ws_bytes[dev][slot] = want;
-    }
-    *out = g_ws[dev][slot];
+    *out = nullptr;
+    if (need == 0) return SCLDPC_OK;
+    if (!s.ptr || s.bytes < need)
+        return set_error(SCLDPC_ERR_BAD_ARG, "%s: this ensemble needs %zu bytes of device workspace (scldpc_workspace_bytes), "
+                         "the caller passed %llu", who, need, (unsigned long long)(s.ptr ? s.bytes : 0));
+    if (reinterpret_cast<uintptr_t>(s.ptr) & 255u)
+        return set_error(SCLDPC_ERR_BAD_ARG, "%s: the workspace must be 256-byte aligned", who);
+    *out = s.ptr;
     return SCLDPC_OK;
 }
 
 }  // namespace scldpc
+
+extern "C" int64_t scldpc_workspace_bytes(int32_t op, const scldpc_code_params *p, int32_t ntrials, int32_t arg0, int32_t arg1)
+{
+    switch (op) {
+    case SCLDPC_WS_SAMPLE:     return scldpc_sample_workspace_query(p, ntrials);
+    case SCLDPC_WS_FULL_BP:    return scldpc_full_bp_workspace_query(p, ntrials, arg0);
+    case SCLDPC_WS_SW_BP:      return scldpc_sw_bp_workspace_query(p, ntrials, arg0);
+    case SCLDPC_WS_PEEL_SWEEP: return scldpc_peel_sweep_workspace_query(p, ntrials, arg0);
+    case SCLDPC_WS_PEEL_PICK:  return scldpc_peel_pick_workspace_query(p, ntrials, arg0, arg1);
+    }
+    return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_workspace_bytes: unknown operation %d", op);
+}
 
 extern "C" int scldpc_abi_version(void) { return SCLDPC_ABI_VERSION; }
 extern "C" const char *scldpc_last_error(void) { return scldpc::g_err; }

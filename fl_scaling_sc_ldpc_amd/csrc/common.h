@@ -17,10 +17,15 @@ inline int nw_of(const scldpc_code_params *p) { return (n_of(p) + 31) / 32; }
 // 0 when the geometry is one the reference's generate_code can produce (BPF:1656-1716).
 int check_params(const scldpc_code_params *p);
 
-// Library-owned device scratch (CN words of ensembles beyond the LDS budget): one allocation per process and
-// device and slot, grown on demand (never inside a stream capture: a growth synchronises the device before freeing).
-// slot 0: CN words of the decoders; slot 1: the big-ensemble sampler's scratch (the two may run on different streams).
-int workspace(size_t bytes, void **out, int slot = 0);
+// Caller-owned device scratch (CN words of ensembles beyond the LDS budget, the big-ensemble sampler's tables): the entry
+// points that can need it take (d_workspace, workspace_bytes) and scldpc_workspace_bytes() says how much — the library
+// allocates nothing and keeps no state between calls.  Launch helpers take a Scratch: in query mode they only report.
+struct Scratch {
+    void *ptr; uint64_t bytes;      // what the caller passed
+    uint64_t *query;                // non-null: store the requirement there and return before launching
+};
+// out = the caller's buffer if it holds `need` bytes; error otherwise.  need == 0: out = nullptr.
+int take_scratch(const char *who, const Scratch &s, size_t need, void **out);
 
 // x / d == umulhi(x, magic) for every x < limit?  (monotone step function: checking the steps suffices)
 inline bool magic_of(int d, int64_t limit, uint32_t *magic)
@@ -43,3 +48,10 @@ constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgr
     } while (0)
 
 }  // namespace scldpc
+
+// per-file requirement queries behind scldpc_workspace_bytes (each runs its launch function's own decision logic)
+int64_t scldpc_full_bp_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t want_rows);
+int64_t scldpc_sw_bp_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t W);
+int64_t scldpc_peel_sweep_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t adj16);
+int64_t scldpc_peel_pick_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t total_size, int32_t rng_mt);
+int64_t scldpc_sample_workspace_query(const scldpc_code_params *p, int32_t ntrials);

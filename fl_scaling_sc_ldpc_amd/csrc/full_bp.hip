@@ -490,14 +490,15 @@ extern "C" int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p)
 static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
                           const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
                           int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                          uint32_t *d_erased_bits, void *stream)
+                          uint32_t *d_erased_bits, const scldpc::Scratch &scratch, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
+    if (scratch.query) *scratch.query = 0;
+    if (!scratch.query && (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits))))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_device: null buffer or negative ntrials");
     if (d_rows && rows_cap <= 0)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_device: d_rows given but rows_cap <= 0");
-    if (ntrials == 0) return SCLDPC_OK;
+    if (ntrials <= 0) return SCLDPC_OK;
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
@@ -522,10 +523,13 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                      "scldpc_full_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
         global_ws = true;
+        const size_t need = (size_t)ntrials * nk * sizeof(uint32_t);
+        if (scratch.query) { *scratch.query = need; return SCLDPC_OK; }
         void *ws = nullptr;
-        if (int rc = scldpc::workspace((size_t)ntrials * nk * sizeof(uint32_t), &ws)) return rc;
+        if (int rc = scldpc::take_scratch("scldpc_full_bp_device", scratch, need, &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
     }
+    if (scratch.query) return SCLDPC_OK;
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
     a.cn_lim = is_term ? nk : p->L * p->cns_pos;                    // BPT:944-948
     a.max_it = max_it; a.rows_cap = traj ? rows_cap : 0;
@@ -556,33 +560,44 @@ extern "C" int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrial
                                      const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                      int32_t max_it, int32_t is_term,
                                      int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                                     uint32_t *d_erased_bits, void *stream)
+                                     uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream)
 {
     return launch_full_bp(p, ntrials, d_vn_adj, false, d_chan_bits, max_it, is_term, d_counters, d_rows, rows_cap,
-                          d_erased_bits, stream);
+                          d_erased_bits, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_full_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                            const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                            int32_t max_it, int32_t is_term,
                                            int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                                           uint32_t *d_erased_bits, void *stream)
+                                           uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream)
 {
     return launch_full_bp(p, ntrials, d_vn_adj16, true, d_chan_bits, max_it, is_term, d_counters, d_rows, rows_cap,
-                          d_erased_bits, stream);
+                          d_erased_bits, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
+}
+
+// workspace of scldpc_full_bp_device(_adj16) / scldpc_full_bp_fixpoint_device(_adj16) for ntrials trials (rows: trajectory mode)
+int64_t scldpc_full_bp_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t want_rows)
+{
+    uint64_t need = 0;
+    int32_t dummy_rows = 0;
+    const int rc = launch_full_bp(p, ntrials, nullptr, true, nullptr, 0, 1, nullptr, want_rows ? &dummy_rows : nullptr,
+                                  want_rows ? 1 : 0, nullptr, scldpc::Scratch{nullptr, 0, &need}, nullptr);
+    return rc ? (int64_t)rc : (int64_t)need;
 }
 
 // The fixpoint of unlimited flooding by chain-following peeling (full_bp_fixpoint_kernel).  Ensembles the packed words do
 // not cover (dv != 4, dv*vns_pos > 4096, LDS) take the level-synchronous kernel: same results, ITERATIONS = flooding iterations.
 static int launch_full_bp_fixpoint(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
                                    const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
-                                   uint32_t *d_erased_bits, void *stream)
+                                   uint32_t *d_erased_bits, const scldpc::Scratch &scratch, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
     Args a{};
     const bool ok = p->dv == 4 && packed_ok(p) && make_layout<Packed>(p, scldpc::kMaxLdsBytes / 2 - 1024, &a.lay) == 0;
     if (!ok)
-        return launch_full_bp(p, ntrials, d_vn_adj, adj16, d_chan_bits, 0, is_term, d_counters, nullptr, 0, d_erased_bits, stream);
+        return launch_full_bp(p, ntrials, d_vn_adj, adj16, d_chan_bits, 0, is_term, d_counters, nullptr, 0, d_erased_bits,
+                              scratch, stream);
     if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_fixpoint_device: null buffer or negative ntrials");
     if (ntrials == 0) return SCLDPC_OK;
@@ -603,14 +618,18 @@ static int launch_full_bp_fixpoint(const scldpc_code_params *p, int32_t ntrials,
 
 extern "C" int scldpc_full_bp_fixpoint_device(const scldpc_code_params *p, int32_t ntrials,
                                               const int32_t *d_vn_adj, const uint32_t *d_chan_bits, int32_t is_term,
-                                              int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                              int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+                                              uint64_t workspace_bytes, void *stream)
 {
-    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj, false, d_chan_bits, is_term, d_counters, d_erased_bits, stream);
+    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj, false, d_chan_bits, is_term, d_counters, d_erased_bits,
+                                   scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                                     const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits, int32_t is_term,
-                                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                                    int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+                                                    uint64_t workspace_bytes, void *stream)
 {
-    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj16, true, d_chan_bits, is_term, d_counters, d_erased_bits, stream);
+    return launch_full_bp_fixpoint(p, ntrials, d_vn_adj16, true, d_chan_bits, is_term, d_counters, d_erased_bits,
+                                   scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }

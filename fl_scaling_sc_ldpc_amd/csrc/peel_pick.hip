@@ -234,15 +234,16 @@ __global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
 static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
                             const uint32_t *d_chan_bits, int32_t total_size, int32_t num_steps,
                             uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
+                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, const scldpc::Scratch &scratch, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits)))
+    if (scratch.query) *scratch.query = 0;
+    if (!scratch.query && (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits))))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_pick_device: null buffer or negative ntrials");
     const int n = scldpc::n_of(p), ncn = scldpc::nk_of(p);
     if (total_size < 0 || total_size > ncn || num_steps < 0)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_pick_device: total_size outside [0,%d] or negative steps", ncn);
-    if (ntrials == 0) return SCLDPC_OK;
+    if (ntrials <= 0) return SCLDPC_OK;
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
     Args a{};
@@ -281,11 +282,14 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_pick_device: needs %zu B of LDS", lds_bytes);
     if (gws) {
         const size_t cn_bytes = (((size_t)ntrials * ncn * sizeof(uint32_t)) + 255) & ~(size_t)255;
+        const size_t need = cn_bytes + (d1g ? (size_t)ntrials * a.nd1 * 8 : 0);
+        if (scratch.query) { *scratch.query = need; return SCLDPC_OK; }
         void *ws = nullptr;
-        if (int rc = scldpc::workspace(cn_bytes + (d1g ? (size_t)ntrials * a.nd1 * 8 : 0), &ws)) return rc;
+        if (int rc = scldpc::take_scratch("scldpc_peel_pick_device", scratch, need, &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
         a.ws_d1 = reinterpret_cast<unsigned long long *>(static_cast<char *>(ws) + cn_bytes);
     }
+    if (scratch.query) return SCLDPC_OK;
     a.moments = reinterpret_cast<unsigned long long *>(d_moments);
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.mt = d_mt_state; a.r1 = d_r1; a.out = d_out;
     void (*kern)(const Args);
@@ -304,18 +308,30 @@ extern "C" int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntri
                                        const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                        int32_t total_size, int32_t num_steps,
                                        uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                       int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
+                                       int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
     return launch_peel_pick(p, ntrials, d_vn_adj, false, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
-                            d_r1, d_moments, d_out, stream);
+                            d_r1, d_moments, d_out, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                              const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                              int32_t total_size, int32_t num_steps,
                                              uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                             int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream)
+                                             int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
     return launch_peel_pick(p, ntrials, d_vn_adj16, true, d_chan_bits, total_size, num_steps, d_mt_state, seed, trial0,
-                            d_r1, d_moments, d_out, stream);
+                            d_r1, d_moments, d_out, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
+}
+
+// workspace of scldpc_peel_pick_device(_adj16) for ntrials trials; rng_mt: the MT19937 state is staged in LDS too
+int64_t scldpc_peel_pick_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t total_size, int32_t rng_mt)
+{
+    uint64_t need = 0;
+    uint32_t dummy = 0;
+    const int rc = launch_peel_pick(p, ntrials, nullptr, true, nullptr, total_size, 0, rng_mt ? &dummy : nullptr, 0, 0,
+                                    nullptr, nullptr, nullptr, scldpc::Scratch{nullptr, 0, &need}, nullptr);
+    return rc ? (int64_t)rc : (int64_t)need;
 }

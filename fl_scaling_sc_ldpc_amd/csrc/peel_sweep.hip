@@ -249,15 +249,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void p
 
 static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
                              const uint32_t *d_chan_bits, int32_t total_size, int32_t sweep_start,
-                             int32_t lost_lo, int32_t lost_hi, int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+                             int32_t lost_lo, int32_t lost_hi, int32_t *d_out, uint32_t *d_lost_bits, const scldpc::Scratch &scratch, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits)))
+    if (scratch.query) *scratch.query = 0;
+    if (!scratch.query && (ntrials < 0 || (ntrials > 0 && (!d_out || !d_vn_adj || !d_chan_bits))))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_sweep_device: null buffer or negative ntrials");
     const int n = scldpc::n_of(p), ncn = scldpc::nk_of(p);
     if (total_size < 0 || total_size > ncn || sweep_start < 0 || lost_lo < 0 || lost_hi > ncn)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_peel_sweep_device: CN ranges outside [0,%d]", ncn);
-    if (ntrials == 0) return SCLDPC_OK;
+    if (ntrials <= 0) return SCLDPC_OK;
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_peel_sweep_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
     Args a{};
@@ -288,10 +289,13 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
     const bool global_ws = mode == 2;
     a.lay.qcap = qcap; a.lay.q0 = take(qcap); a.lay.q1 = take(qcap); a.lay.total = off;
     if (global_ws) {
+        const size_t need = (size_t)ntrials * ncn * sizeof(uint32_t);
+        if (scratch.query) { *scratch.query = need; return SCLDPC_OK; }
         void *ws = nullptr;
-        if (int rc = scldpc::workspace((size_t)ntrials * ncn * sizeof(uint32_t), &ws)) return rc;
+        if (int rc = scldpc::take_scratch("scldpc_peel_sweep_device", scratch, need, &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
     }
+    if (scratch.query) return SCLDPC_OK;
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.ncn = ncn;
     a.total_size = total_size; a.sweep_start = sweep_start; a.lost_lo = lost_lo; a.lost_hi = lost_hi;
     if (!scldpc::magic_of(p->vns_pos, n > 4096 ? n : 4096, &a.magic_v) || !scldpc::magic_of(p->cns_pos, ncn, &a.magic_c))
@@ -313,17 +317,28 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
 extern "C" int scldpc_peel_sweep_device(const scldpc_code_params *p, int32_t ntrials,
                                         const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                         int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
-                                        int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+                                        int32_t *d_out, uint32_t *d_lost_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
     return launch_peel_sweep(p, ntrials, d_vn_adj, false, d_chan_bits, total_size, sweep_start, lost_lo, lost_hi,
-                             d_out, d_lost_bits, stream);
+                             d_out, d_lost_bits, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_peel_sweep_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                               const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                               int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
-                                              int32_t *d_out, uint32_t *d_lost_bits, void *stream)
+                                              int32_t *d_out, uint32_t *d_lost_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
     return launch_peel_sweep(p, ntrials, d_vn_adj16, true, d_chan_bits, total_size, sweep_start, lost_lo, lost_hi,
-                             d_out, d_lost_bits, stream);
+                             d_out, d_lost_bits, scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
+}
+
+// workspace of scldpc_peel_sweep_device(_adj16) for ntrials trials
+int64_t scldpc_peel_sweep_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t adj16)
+{
+    uint64_t need = 0;
+    const int rc = launch_peel_sweep(p, ntrials, nullptr, adj16 != 0, nullptr, 0, 0, 0, 0, nullptr, nullptr,
+                                     scldpc::Scratch{nullptr, 0, &need}, nullptr);
+    return rc ? (int64_t)rc : (int64_t)need;
 }

@@ -422,17 +422,18 @@ __global__ __launch_bounds__(kThreads) void sample_philox_big_kernel(const SArgs
 
 template <bool ADJ16>
 int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t trial0, int32_t ntrials, double eps,
-           int32_t ndoped, const int32_t *doped_positions, void *d_adj, uint32_t *d_chan_bits, void *stream,
-           const char *who)
+           int32_t ndoped, const int32_t *doped_positions, void *d_adj, uint32_t *d_chan_bits,
+           const scldpc::Scratch &scratch, void *stream, const char *who)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_adj || !d_chan_bits)))
+    if (scratch.query) *scratch.query = 0;
+    if (!scratch.query && (ntrials < 0 || (ntrials > 0 && (!d_adj || !d_chan_bits))))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
     if (ndoped < 0 || ndoped > kMaxDoped || (ndoped > 0 && !doped_positions))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: 0 <= ndoped <= %d", who, kMaxDoped);
     if (!(eps >= 0.0 && eps <= 1.0))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: eps=%g outside [0,1]", who, eps);
-    if (ntrials == 0) return SCLDPC_OK;
+    if (ntrials <= 0) return SCLDPC_OK;
 
     SArgs a{};
     a.dv = p->dv; a.dc = p->dc; a.L = p->L; a.cns_pos = p->cns_pos; a.vns_pos = p->vns_pos;
@@ -492,8 +493,9 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
 
     if (big) {
         const size_t stride = (((size_t)a.S * (12 + 2 * p->dv)) + 255) & ~(size_t)255;
+        if (scratch.query) { *scratch.query = stride * (size_t)ntrials; return SCLDPC_OK; }
         void *ws = nullptr;
-        if (int rc = scldpc::workspace(stride * (size_t)ntrials, &ws, 1)) return rc;
+        if (int rc = scldpc::take_scratch(who, scratch, stride * (size_t)ntrials, &ws)) return rc;
         void (*kb)(const SArgs, char *, size_t) = a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16>
                                                                  : sample_philox_big_kernel<8, ADJ16>;
         SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb),
@@ -503,6 +505,7 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         SCLDPC_HIP_CHECK(hipGetLastError());
         return SCLDPC_OK;
     }
+    if (scratch.query) return SCLDPC_OK;
     const int kmax = ((a.S + 3) / 4 + kThreads - 1) / kThreads;     // 1 or 2
     const int rows = a.nb / kThreads;                               // 1, 2, 4 or 8 rows of 64 per wave
     void (*kern)(const SArgs) = nullptr;
@@ -529,19 +532,21 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
 
 extern "C" int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
                                            int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
-                                           int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream)
+                                           int32_t *d_vn_adj, uint32_t *d_chan_bits, void *d_workspace,
+                                           uint64_t workspace_bytes, void *stream)
 {
     return launch<false>(p, SCLDPC_ENS_OLMOS, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits,
-                         stream, "scldpc_sample_philox_device");
+                         scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream, "scldpc_sample_philox_device");
 }
 
 extern "C" int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
                                                  int32_t ntrials, double eps, int32_t ndoped,
                                                  const int32_t *doped_positions, uint16_t *d_vn_adj16,
-                                                 uint32_t *d_chan_bits, void *stream)
+                                                 uint32_t *d_chan_bits, void *d_workspace, uint64_t workspace_bytes,
+                                                 void *stream)
 {
     return launch<true>(p, SCLDPC_ENS_OLMOS, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_chan_bits,
-                        stream, "scldpc_sample_philox_device_adj16");
+                        scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream, "scldpc_sample_philox_device_adj16");
 }
 
 extern "C" int scldpc_sample_philox_ensemble_device(const scldpc_code_params *p, int32_t ensemble, uint64_t seed,
@@ -549,6 +554,15 @@ extern "C" int scldpc_sample_philox_ensemble_device(const scldpc_code_params *p,
                                                     const int32_t *doped_positions, int32_t *d_vn_adj,
                                                     uint32_t *d_chan_bits, void *stream)
 {
-    return launch<false>(p, ensemble, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits, stream,
-                         "scldpc_sample_philox_ensemble_device");
+    return launch<false>(p, ensemble, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj, d_chan_bits,
+                         scldpc::Scratch{nullptr, 0, nullptr}, stream, "scldpc_sample_philox_ensemble_device");
+}
+
+// workspace of scldpc_sample_philox_device(_adj16) for ntrials trials (ensembles beyond 8192 sockets per position)
+int64_t scldpc_sample_workspace_query(const scldpc_code_params *p, int32_t ntrials)
+{
+    uint64_t need = 0;
+    const int rc = launch<true>(p, SCLDPC_ENS_OLMOS, 0, 0, ntrials, 0.5, 0, nullptr, nullptr, nullptr,
+                                scldpc::Scratch{nullptr, 0, &need}, nullptr, "scldpc_workspace_bytes");
+    return rc ? (int64_t)rc : (int64_t)need;
 }

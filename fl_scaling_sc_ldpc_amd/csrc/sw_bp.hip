@@ -272,14 +272,15 @@ int make_layout(const scldpc_code_params *p, int W, Layout *lay)
 
 static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16, bool classical,
                         const uint32_t *d_chan_bits, int32_t W, int32_t max_it, int32_t init_it,
-                        int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                        int32_t *d_counters, uint32_t *d_erased_bits, const scldpc::Scratch &scratch, void *stream)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits)))
+    if (scratch.query) *scratch.query = 0;
+    if (!scratch.query && (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj || !d_chan_bits))))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: null buffer or negative ntrials");
     if (W < 1 || max_it < 0 || init_it < 0)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_sw_bp_device: need W >= 1, max_it >= 0, init_it >= 0");
-    if (ntrials == 0) return SCLDPC_OK;
+    if (ntrials <= 0) return SCLDPC_OK;
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     if (p->dc > 15 || p->dv > 8 || (int64_t)p->dc * n >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: needs dc <= 15, dv <= 8, dc*n < 2^24");
@@ -292,10 +293,13 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
             return scldpc::set_error(SCLDPC_ERR_TOO_LARGE,
                                      "scldpc_sw_bp_device: n=%d VN bits + nk=%d scan bits do not fit 160 KiB of LDS", n, nk);
         gws = true;
+        const size_t need = (size_t)ntrials * nk * sizeof(uint32_t);
+        if (scratch.query) { *scratch.query = need; return SCLDPC_OK; }
         void *ws = nullptr;
-        if (int rc = scldpc::workspace((size_t)ntrials * nk * sizeof(uint32_t), &ws)) return rc;
+        if (int rc = scldpc::take_scratch("scldpc_sw_bp_device", scratch, need, &ws)) return rc;
         a.ws = static_cast<uint32_t *>(ws);
     }
+    if (scratch.query) return SCLDPC_OK;
     if (!scldpc::magic_of(p->vns_pos, n > 4096 ? n : 4096, &a.magic_v) || !scldpc::magic_of(p->cns_pos, nk, &a.magic_c))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_sw_bp_device: reciprocal division inexact for this size");
     a.dv = p->dv; a.L = p->L; a.vns_pos = p->vns_pos; a.cns_pos = p->cns_pos; a.n = n; a.nk = nk;
@@ -319,31 +323,48 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
 extern "C" int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                                    const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                    int32_t W, int32_t max_it, int32_t init_it,
-                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                   int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj, false, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj, false, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits,
+                        scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                          const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                          int32_t W, int32_t max_it, int32_t init_it,
-                                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                         int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj16, true, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj16, true, false, d_chan_bits, W, max_it, init_it, d_counters, d_erased_bits,
+                        scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_swc_bp_device(const scldpc_code_params *p, int32_t ntrials,
                                     const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                                     int32_t W, int32_t max_it,
-                                    int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                    int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj, false, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj, false, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits,
+                        scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
 }
 
 extern "C" int scldpc_swc_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                           const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                           int32_t W, int32_t max_it,
-                                          int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                                          int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace,
+        uint64_t workspace_bytes, void *stream)
 {
-    return launch_sw_bp(p, ntrials, d_vn_adj16, true, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits, stream);
+    return launch_sw_bp(p, ntrials, d_vn_adj16, true, true, d_chan_bits, W, max_it, max_it, d_counters, d_erased_bits,
+                        scldpc::Scratch{d_workspace, workspace_bytes, nullptr}, stream);
+}
+
+// workspace of scldpc_sw_bp_device / scldpc_swc_bp_device (and their _adj16 forms) for ntrials trials and window W
+int64_t scldpc_sw_bp_workspace_query(const scldpc_code_params *p, int32_t ntrials, int32_t W)
+{
+    uint64_t need = 0;
+    const int rc = launch_sw_bp(p, ntrials, nullptr, true, false, nullptr, W, 1, 1, nullptr, nullptr,
+                                scldpc::Scratch{nullptr, 0, &need}, nullptr);
+    return rc ? (int64_t)rc : (int64_t)need;
 }

@@ -26,6 +26,22 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+WS_SAMPLE, WS_FULL_BP, WS_SW_BP, WS_PEEL_SWEEP, WS_PEEL_PICK = range(5)      # SCLDPC_WS_*
+
+
+def _workspace(op, p, ntrials, device, arg0=0, arg1=0):
+    """(device pointer, bytes) of a caller-owned workspace for one call, or (None, 0) when the ensemble needs none.
+    A fresh torch buffer per call: the caching allocator hands memory back only to the stream that used it, so calls
+    on different streams never share scratch (the library itself allocates nothing)."""
+    nbytes = lib().scldpc_workspace_bytes(op, C.byref(p), int(ntrials), int(arg0), int(arg1))
+    if nbytes < 0:
+        check(int(nbytes))
+    if nbytes == 0:
+        return None, 0, None
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return buf.data_ptr(), int(nbytes), buf
+
+
 def _require_gpu():
     if not torch.cuda.is_available():
         raise ScldpcError("no HIP device visible: the decoders run only on the GPU (no CPU fallback)")
@@ -117,8 +133,9 @@ def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=
                                                          d_ch.data_ptr(), _stream_ptr(d_adj.device)))
         return d_adj, d_ch
     fn = lib().scldpc_sample_philox_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sample_philox_device
+    ws, wsb, _keep = _workspace(WS_SAMPLE, p, ntrials, d_adj.device)
     check(fn(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size, dptr, d_adj.data_ptr(),
-             d_ch.data_ptr(), _stream_ptr(d_adj.device)))
+             d_ch.data_ptr(), ws, wsb, _stream_ptr(d_adj.device)))
     return d_adj, d_ch
 
 
@@ -202,9 +219,10 @@ def full_bp(p, d_adj, d_chan, max_it=0, is_term=True, rows_cap=0, want_erased=Fa
     rows = torch.zeros((T, rows_cap, 3), dtype=torch.int32, device=dev) if rows_cap > 0 else None
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
     fn = lib().scldpc_full_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_full_bp_device
+    ws, wsb, _keep = _workspace(WS_FULL_BP, p, T, dev, 1 if rows is not None else 0)
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(max_it), 1 if is_term else 0,
              counters.data_ptr(), rows.data_ptr() if rows is not None else None, int(rows_cap),
-             erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+             erased.data_ptr() if erased is not None else None, ws, wsb, _stream_ptr(dev)))
     return {"counters": counters, "rows": rows, "erased": erased}
 
 
@@ -221,8 +239,9 @@ def full_bp_fixpoint(p, d_adj, d_chan, is_term=True, want_erased=False, counters
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
     fn = lib().scldpc_full_bp_fixpoint_device_adj16 if _is_adj16(d_adj) else lib().scldpc_full_bp_fixpoint_device
+    ws, wsb, _keep = _workspace(WS_FULL_BP, p, T, dev, 0)
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), 1 if is_term else 0, counters.data_ptr(),
-             erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+             erased.data_ptr() if erased is not None else None, ws, wsb, _stream_ptr(dev)))
     return {"counters": counters, "rows": None, "erased": erased}
 
 
@@ -255,14 +274,15 @@ def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=No
     if counters is None:
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    ws, wsb, _keep = _workspace(WS_SW_BP, p, T, dev, int(W))
     if classical:
         fn = lib().scldpc_swc_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_swc_bp_device
         check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it),
-                 counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+                 counters.data_ptr(), erased.data_ptr() if erased is not None else None, ws, wsb, _stream_ptr(dev)))
         return {"counters": counters, "erased": erased}
     fn = lib().scldpc_sw_bp_device_adj16 if _is_adj16(d_adj) else lib().scldpc_sw_bp_device
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(W), int(max_it), int(init_it),
-             counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+             counters.data_ptr(), erased.data_ptr() if erased is not None else None, ws, wsb, _stream_ptr(dev)))
     return {"counters": counters, "erased": erased}
 
 
@@ -308,9 +328,10 @@ def peel_sweep(p, d_adj, d_chan, total_size, sweep_start=0, lost_lo=0, lost_hi=N
     out = torch.empty((T, 8), dtype=torch.int32, device=dev)
     lost = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_lost else None
     fn = lib().scldpc_peel_sweep_device_adj16 if _is_adj16(d_adj) else lib().scldpc_peel_sweep_device
+    ws, wsb, _keep = _workspace(WS_PEEL_SWEEP, p, T, dev, 1 if _is_adj16(d_adj) else 0)
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(total_size), int(sweep_start), int(lost_lo),
              int(total_size if lost_hi is None else lost_hi), out.data_ptr(),
-             lost.data_ptr() if lost is not None else None, _stream_ptr(dev)))
+             lost.data_ptr() if lost is not None else None, ws, wsb, _stream_ptr(dev)))
     return {"out": out, "lost": lost}
 
 
@@ -326,10 +347,11 @@ def peel_pick(p, d_adj, d_chan, total_size, num_steps, mt_state=None, seed=0, tr
     if mt_state is not None:
         assert mt_state.is_cuda and mt_state.dtype == torch.int32 and tuple(mt_state.shape) == (T, 625)
     fn = lib().scldpc_peel_pick_device_adj16 if _is_adj16(d_adj) else lib().scldpc_peel_pick_device
+    ws, wsb, _keep = _workspace(WS_PEEL_PICK, p, T, dev, int(total_size), 1 if mt_state is not None else 0)
     check(fn(C.byref(p), T, d_adj.data_ptr(), d_chan.data_ptr(), int(total_size), int(num_steps),
              mt_state.data_ptr() if mt_state is not None else None, int(seed), int(trial0),
              r1.data_ptr() if r1 is not None else None, moments.data_ptr() if moments is not None else None,
-             out.data_ptr(), _stream_ptr(dev)))
+             out.data_ptr(), ws, wsb, _stream_ptr(dev)))
     return {"out": out, "r1": r1, "moments": moments}
 
 

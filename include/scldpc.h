@@ -12,9 +12,15 @@
  *   PD  = simulators_sc_ldpc/peeling_decoding/peeling_decoding.py
  *
  * Conventions: plain pointers and sizes, caller-owned buffers, `int` status return (0 = OK,
- * negative = error, text via scldpc_last_error()), no globals shared between calls.  Pointers
+ * negative = error, text via scldpc_last_error(), thread-local), no globals shared between calls.  Pointers
  * named d_* are DEVICE pointers (HIP); `stream` is a hipStream_t passed as void* (NULL = default
- * stream).  Device entry points only enqueue work; they never synchronise.
+ * stream).  Device entry points only enqueue work; they never synchronise, allocate or free — so they can be
+ * captured into a hipGraph and called concurrently on different streams.
+ *
+ * Workspace: ensembles whose per-CN state exceeds the LDS (N >= 2500 decoders, random-pick peeling at N >= 2000, the
+ * sampler beyond 8192 sockets per position) keep it in device memory the CALLER owns: pass (d_workspace,
+ * workspace_bytes) with at least scldpc_workspace_bytes(op, ...) bytes, 256-byte aligned, not shared with a call that
+ * may run at the same time.  The query returns 0 when the ensemble needs none (NULL / 0 may then be passed).
  *
  * Data layout (one "trial" = one sampled code + one channel realisation = one reference "frame"):
  *   vn_adj   int32 [ntrials][n][dv]       CN index of edge i of VN j   (VNdegree[j][1+i], BPF:87)
@@ -33,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SCLDPC_ABI_VERSION 1
+#define SCLDPC_ABI_VERSION 2
 
 enum {
     SCLDPC_OK = 0,
@@ -42,6 +48,16 @@ enum {
     SCLDPC_ERR_HIP = -3,            /* a HIP runtime call failed                     */
     SCLDPC_ERR_NO_DEVICE = -4
 };
+
+/* Device workspace an entry point needs for `ntrials` trials of ensemble p (0: none), or a negative error:
+ *   SCLDPC_WS_SAMPLE      scldpc_sample_philox_device(_adj16)
+ *   SCLDPC_WS_FULL_BP     scldpc_full_bp_device(_adj16), scldpc_full_bp_fixpoint_device(_adj16); arg0 != 0: with d_rows
+ *   SCLDPC_WS_SW_BP       scldpc_sw_bp_device(_adj16), scldpc_swc_bp_device(_adj16);             arg0 = W
+ *   SCLDPC_WS_PEEL_SWEEP  scldpc_peel_sweep_device(_adj16);                                      arg0 != 0: the _adj16 form
+ *   SCLDPC_WS_PEEL_PICK   scldpc_peel_pick_device(_adj16);  arg0 = total_size, arg1 != 0: with d_mt_state */
+enum { SCLDPC_WS_SAMPLE = 0, SCLDPC_WS_FULL_BP = 1, SCLDPC_WS_SW_BP = 2, SCLDPC_WS_PEEL_SWEEP = 3, SCLDPC_WS_PEEL_PICK = 4 };
+struct scldpc_code_params;
+int64_t scldpc_workspace_bytes(int32_t op, const struct scldpc_code_params *p, int32_t ntrials, int32_t arg0, int32_t arg1);
 
 /* Ensemble geometry — the compile-time #defines of BPF:22-37 as run-time parameters.
  * Naming trap: cns_pos = Def_M = Def_CNsPos; vns_pos = Def_VNsPos = "N" of the papers = Python's M (PD:18). */
@@ -111,7 +127,7 @@ int     scldpc_sample_glibc_next_host(const scldpc_code_params *p, void *state, 
  * a run over calls / GPUs gives identical codes.  d_vn_adj [ntrials][n][dv], d_chan_bits [ntrials][nw]. */
 int scldpc_sample_philox_device(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
                                 int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
-                                int32_t *d_vn_adj, uint32_t *d_chan_bits, void *stream);
+                                int32_t *d_vn_adj, uint32_t *d_chan_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* The other ensembles of the reference's Python simulators, same keying, global CN ids (int32 rows):
  *   SCLDPC_ENS_TAIL_BITING  sc_ldpc.gen_slots_tail_biting (sc_ldpc.py:41-62): L permutations, edge i of VN position q
@@ -139,7 +155,7 @@ int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
                           const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                           int32_t max_it, int32_t is_term,
                           int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                          uint32_t *d_erased_bits, void *stream);
+                          uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* decodeBP with no iteration cap, when only what it converges to is wanted (the reference's bp_lim_iter with MAX_IT beyond
  * reach, BPF:2080-2083, prints nothing that depends on the iteration count): same counters as scldpc_full_bp_device with
@@ -148,10 +164,10 @@ int scldpc_full_bp_device(const scldpc_code_params *p, int32_t ntrials,
  * release opens instead of waiting for the next flooding iteration (full_bp.hip). */
 int scldpc_full_bp_fixpoint_device(const scldpc_code_params *p, int32_t ntrials,
                                    const int32_t *d_vn_adj, const uint32_t *d_chan_bits, int32_t is_term,
-                                   int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                                   int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                          const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits, int32_t is_term,
-                                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                                         int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* The same pair — generate_code + channel_doped (BPF:1656-1761, 1547-1574), then decodeBP to its fixpoint (BPF:900-1140) —
  * for the (dv = 4, dc = 8) chain with at most 4096 sockets per CN position (N <= 1024: the BASELINE ensemble), in the form
@@ -177,18 +193,18 @@ int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntr
 int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                         const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                         int32_t W, int32_t max_it, int32_t init_it,
-                        int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                        int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* decodeBP_SW, classical window — the variant kept in BPF:627-897 (its call is commented out at BPF:2137-2138):
  * L+dv-1 windows, VNs [posW-ms, posW+W), position posW-ms decided when window posW closes, max_it per window. */
 int scldpc_swc_bp_device(const scldpc_code_params *p, int32_t ntrials,
                          const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                          int32_t W, int32_t max_it,
-                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                         int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_swc_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                int32_t W, int32_t max_it,
-                               int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                               int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* Compact adjacency variants.  d_vn_adj16 is uint16 [ntrials][n][dv]: the CN index LOCAL to its position
  * (0 .. cns_pos-1).  Edge i of a VN at position pos always lands in CN position pos+i (BPF:1712), so the
@@ -196,16 +212,16 @@ int scldpc_swc_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
  * dv = 4); same results bit for bit.  Requires cns_pos <= 65536. */
 int scldpc_sample_philox_device_adj16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
                                       int32_t ntrials, double eps, int32_t ndoped, const int32_t *doped_positions,
-                                      uint16_t *d_vn_adj16, uint32_t *d_chan_bits, void *stream);
+                                      uint16_t *d_vn_adj16, uint32_t *d_chan_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_full_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                 const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                 int32_t max_it, int32_t is_term,
                                 int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
-                                uint32_t *d_erased_bits, void *stream);
+                                uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                               const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                               int32_t W, int32_t max_it, int32_t init_it,
-                              int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+                              int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Python peeling path (PD = simulators_sc_ldpc/peeling_decoding/peeling_decoding.py)
@@ -224,11 +240,11 @@ int scldpc_sw_bp_device_adj16(const scldpc_code_params *p, int32_t ntrials,
 int scldpc_peel_sweep_device(const scldpc_code_params *p, int32_t ntrials,
                              const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                              int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
-                             int32_t *d_out, uint32_t *d_lost_bits, void *stream);
+                             int32_t *d_out, uint32_t *d_lost_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_peel_sweep_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                    const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                    int32_t total_size, int32_t sweep_start, int32_t lost_lo, int32_t lost_hi,
-                                   int32_t *d_out, uint32_t *d_lost_bits, void *stream);
+                                   int32_t *d_out, uint32_t *d_lost_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* One trial of simulate_peeling_decoder_ldpc's loop body (PD:750-785): random-pick peeling with the
  * degree-1-CN trajectory.  num_steps = int(M*num_positions*(e+0.1)) (PD:721).
@@ -244,12 +260,12 @@ int scldpc_peel_pick_device(const scldpc_code_params *p, int32_t ntrials,
                             const int32_t *d_vn_adj, const uint32_t *d_chan_bits,
                             int32_t total_size, int32_t num_steps,
                             uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream);
+                            int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int scldpc_peel_pick_device_adj16(const scldpc_code_params *p, int32_t ntrials,
                                   const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
                                   int32_t total_size, int32_t num_steps,
                                   uint32_t *d_mt_state, uint64_t seed, uint64_t trial0,
-                                  int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *stream);
+                                  int32_t *d_r1, int64_t *d_moments, int32_t *d_out, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* Integer moments of a batch of trajectories, the device half of main_simulate_variance (PD:1264-1294) /
  * calc_nu_chunk (fl_scaling/est_scaling_params.py:90-94,131-138): d_moments int64 [3][ncols], accumulated in

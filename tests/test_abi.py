@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(L):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), f"libscldpc_hip.so does not export {name}"
-    assert L.scldpc_abi_version() == 1
+    assert L.scldpc_abi_version() == 2
 
 
 def test_header_is_plain_c():
@@ -52,11 +52,22 @@ def test_error_paths_without_device(L):
     assert L.scldpc_full_bp_lds_bytes(C.byref(big)) <= 160 * 1024
     huge = _lib.CodeParams(4, 8, 50, 50000, 100000)        # N = 100000: even the VN bitmap exceeds the LDS
     assert L.scldpc_full_bp_lds_bytes(C.byref(huge)) > 160 * 1024
-    assert L.scldpc_full_bp_device(C.byref(ok), -1, None, None, 0, 1, None, None, 0, None, None) == -1
-    assert L.scldpc_full_bp_device(C.byref(ok), 0, None, None, 0, 1, None, None, 0, None, None) == 0    # empty batch
-    assert L.scldpc_full_bp_device(C.byref(ok), 1, None, None, 0, 1, None, None, 0, None, None) == -1   # null buffers
-    assert L.scldpc_sample_philox_device(C.byref(ok), 1, 0, 1, 1.5, 0, None, None, None, None) == -1
-    assert L.scldpc_sw_bp_device(C.byref(ok), 1, None, None, 0, 1, 1, None, None, None) == -1
+    assert L.scldpc_full_bp_device(C.byref(ok), -1, None, None, 0, 1, None, None, 0, None, None, 0, None) == -1
+    assert L.scldpc_full_bp_device(C.byref(ok), 0, None, None, 0, 1, None, None, 0, None, None, 0, None) == 0    # empty batch
+    assert L.scldpc_full_bp_device(C.byref(ok), 1, None, None, 0, 1, None, None, 0, None, None, 0, None) == -1   # null buffers
+    assert L.scldpc_sample_philox_device(C.byref(ok), 1, 0, 1, 1.5, 0, None, None, None, None, 0, None) == -1
+    assert L.scldpc_sw_bp_device(C.byref(ok), 1, None, None, 0, 1, 1, None, None, None, 0, None) == -1
+    # caller-owned workspace: what each operation needs, without a device (pure host arithmetic)
+    WS = dict(sample=0, full_bp=1, sw_bp=2, peel_sweep=3, peel_pick=4)
+    assert L.scldpc_workspace_bytes(WS["full_bp"], C.byref(ok), 4096, 0, 0) == 0            # N = 1000: everything in LDS
+    assert L.scldpc_workspace_bytes(WS["sample"], C.byref(ok), 4096, 0, 0) == 0
+    assert L.scldpc_workspace_bytes(WS["full_bp"], C.byref(big), 100, 0, 0) == 100 * (53 * 5000) * 4   # one word per CN
+    assert L.scldpc_workspace_bytes(WS["sw_bp"], C.byref(big), 100, 10, 0) == 100 * (53 * 5000) * 4
+    assert L.scldpc_workspace_bytes(WS["sample"], C.byref(big), 10, 0, 0) > 0
+    assert L.scldpc_workspace_bytes(WS["peel_pick"], C.byref(big), 8, 250000, 0) >= 8 * (53 * 5000) * 4 + 8 * 3907 * 8
+    assert L.scldpc_workspace_bytes(WS["peel_sweep"], C.byref(ok), 8, 1, 0) == 0
+    assert L.scldpc_workspace_bytes(99, C.byref(ok), 8, 0, 0) == -1
+    assert L.scldpc_workspace_bytes(WS["full_bp"], C.byref(bad), 8, 0, 0) == -1
     with pytest.raises(_lib.ScldpcError):
         _lib.check(-1)
 
