@@ -14,7 +14,9 @@ def test_fresh_seeds(oracle, variant, M, L, decoders, kw):
     O = oracle
     if not O.have_ref(variant, M, L):
         pytest.skip("oracle/_ref not built (no /root/reference here): golden fixtures are the pin")
-    rng = np.random.RandomState(hash((variant, M, L)) % 2**31)
+    # a fixed seed per case (zlib.crc32 of its name: str hashes are randomised per process, these are not)
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(repr((variant, M, L, sorted(kw.items()))).encode()) % 2**31)
     p = O.Params(4, 8, L, M, 2 * M)
     for eps in (0.33, 0.46, 0.5, 0.58):
         seed0 = int(rng.randint(1, 2**30))

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSVs that tools/profile.sh leaves in gpurun_out/prof_<tag>/ into
 profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats table, our kernels only),
-profiles/<tag>_pmc.json (FETCH_SIZE / WRITE_SIZE per kernel, own passes) and profiles/traffic.json
-(the number bench.py reports as roofline.traffic).
+profiles/<tag>_pmc.json (FETCH_SIZE / WRITE_SIZE / L2 requests per kernel, separate passes) and profiles/traffic.json
+(what bench.py reports as roofline.traffic / traffic_raw).
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB
-(hbm_bytes = (FETCH_SIZE + WRITE_SIZE)·1024) and on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B,
-so the read side is doubled for wide coalesced streams (our adjacency reads are 16 B/lane).
+HBM bytes (MI355X_MICROARCH.md §HBM + our own calibration, tools/calib, profiles/<tag>_calibration.txt):
+  * counters are in KiB: raw bytes = (FETCH_SIZE + WRITE_SIZE) * 1024;
+  * FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but a request moves 128 B — measured here for a 16-B-per-lane stream (4 GiB read:
+    33.5 M requests) AND for random 8-byte / 16-byte row gathers (one request per gather, the same ~48 G requests/s
+    ceiling as the stream) — so the corrected read bytes are RDREQ x 128 = 2 x FETCH_SIZE for every pattern our kernels use;
+  * WRITE_SIZE is exact for our 8- and 16-byte-per-lane coalesced stores (calibrated: 4 GiB stored reads 4 194 304 KiB).
 """
 import collections
 import csv
@@ -16,7 +19,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("full_bp_fixpoint_kernel", "full_bp_kernel", "sample_philox_kernel", "sw_bp_kernel", "accumulate_run_kernel", "peel")
+KERNELS = ("full_bp_small_kernel", "sample_philox_v2_kernel", "full_bp_fixpoint_kernel", "full_bp_kernel", "sample_philox_kernel",
+           "sample_philox_big_kernel", "sw_bp_kernel", "accumulate_run_kernel", "peel_pick_kernel", "peel_sweep_kernel",
+           "stream_bp_kernel")
 
 
 def short(name):
@@ -27,8 +32,8 @@ def short(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384      # bench.py's default batch
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32768      # bench.py's default batch
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -44,33 +49,42 @@ def main():
                                            "MaxNs", "StdDev")])
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
-    for kind in ("pmc_fetch", "pmc_write"):
-        for path in [newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))]:
-            for r in csv.DictReader(open(path)):
-                k = short(r["Kernel_Name"])
-                if k:
-                    pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    meta[k] = dict(grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]),
-                                   vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]))
-    out = {"tag": tag, "trials_per_launch": batch, "units": "counter values are KiB per dispatch, mean over dispatches",
+    for kind in ("pmc_fetch", "pmc_write", "pmc_rdreq"):
+        files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            k = short(r["Kernel_Name"])
+            if k:
+                pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta[k] = dict(grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]),
+                               vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]))
+    mean = lambda v: sum(v) / len(v) if v else None
+    out = {"tag": tag, "trials_per_launch": batch, "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch, mean over dispatches",
            "kernels": {}}
+    traffic = {}
     for k, c in pmc.items():
-        fetch = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"])) if "FETCH_SIZE" in c else None
-        write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])) if "WRITE_SIZE" in c else None
-        e = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "dispatches": len(c.get("FETCH_SIZE", [])), **meta[k]}
+        fetch, write = mean(c.get("FETCH_SIZE")), mean(c.get("WRITE_SIZE"))
+        rdreq, hit, miss = mean(c.get("TCC_EA0_RDREQ_sum")), mean(c.get("TCC_HIT_sum")), mean(c.get("TCC_MISS_sum"))
+        e = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "TCC_EA0_RDREQ": rdreq, "TCC_HIT": hit, "TCC_MISS": miss,
+             "dispatches": len(c.get("FETCH_SIZE", [])), **meta[k]}
         if fetch is not None and write is not None:
             e["hbm_bytes_per_launch_raw"] = (fetch + write) * 1024
-            e["hbm_bytes_per_launch_corrected"] = (2 * fetch + write) * 1024      # gfx950: FETCH_SIZE x 2
+            e["hbm_bytes_per_launch_corrected"] = (2 * fetch + write) * 1024      # 128 B per read request (calibrated)
             e["hbm_bytes_per_trial_corrected"] = e["hbm_bytes_per_launch_corrected"] / batch
+            if rdreq:
+                e["read_requests_per_trial"] = rdreq / batch
+                e["l2_hit_rate"] = hit / (hit + miss) if hit is not None and miss else None
+            traffic[k] = {"hbm_bytes": e["hbm_bytes_per_launch_corrected"], "hbm_bytes_raw": e["hbm_bytes_per_launch_raw"],
+                          "rdreq": rdreq}
         out["kernels"][k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-    dom = "full_bp_fixpoint_kernel" if "full_bp_fixpoint_kernel" in out["kernels"] else "full_bp_kernel"   # the bench's decoder
-    if dom in out["kernels"] and "hbm_bytes_per_launch_corrected" in out["kernels"][dom]:
-        json.dump({"workload": "(4,8) SC-LDPC L=50 N=1000 eps=0.48 full BP unlimited iterations", "batch": batch,
-                   "kernel": dom,
-                   "full_bp_hbm_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch_corrected"],
-                   "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2)"},
-                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    json.dump({"workload": "(4,8) SC-LDPC L=50 N=1000 eps=0.48 full BP unlimited iterations", "batch": batch,
+               "kernels": traffic,
+               "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum, separate "
+                         "passes of `python bench.py --steps 2 --warmup 1`; read bytes = 128 B x requests = 2 x FETCH_SIZE, "
+                         f"calibrated by tools/calib -> profiles/{tag}_calibration.txt)"},
+              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
