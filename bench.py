@@ -410,7 +410,7 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
     L_CHAIN, N_POS, W, IT = 100, 2000, 10, 20
     EPS = 0.47 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
-    B = a.batch or 2048
+    B = a.batch or 8192
     d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev)
     d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
     d_cnt = torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev)
@@ -459,9 +459,9 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u32", "data": "synthetic",
            "config": {"workload": f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} decodeBP_SW W={W} I_max={IT} I_init={IT}",
-                      "trials_per_gpu_per_step": B, "step": "device sample -> decodeBP_SW -> plr_computation",
+                      "trials_per_gpu_per_step": B, "step": "device sample -> CN->socket table -> decodeBP_SW (window state in LDS) -> plr_computation",
                       "parallelism": f"trial-sharded x{world} (the eps grid shards by point in bp_decoding.py)"},
-           "roofline": {"bound": "hbm", "kernel": "sw_bp_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "sw_ring_kernel (+ cn_sockets_kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_trial": share, "ms_per_launch": ms_w,
                         "literal_flooding": {"bytes": "8*E_w*sum I, E_w = W*N*dv", "sum_iterations": r["iterations"],
                                              "equivalent_GBs": lit, "x_peak": lit / HBM_PEAK_GBS},

@@ -35,6 +35,7 @@ EXPORTS = (
     "scldpc_sample_philox_cn16_supported", "scldpc_sample_philox_device_cn16",
     "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16",
     "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
+    "scldpc_sw_bp_ring_supported", "scldpc_cn_sockets_device", "scldpc_sw_bp_ring_device",
 )
 
 
@@ -117,6 +118,9 @@ def lib():
     L.scldpc_stream_run_device.argtypes = [pp, i32, u64, u64, dbl, i32, i32, vp, i32, vp, vp, vp, vp]
     L.scldpc_stream_glibc_inputs_host.argtypes = [pp, u32, dbl, i32, vp, i32, vp, vp]
     L.scldpc_stream_run_device_inputs.argtypes = [pp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i64, vp]
+    L.scldpc_sw_bp_ring_supported.argtypes = [pp, i32]
+    L.scldpc_cn_sockets_device.argtypes = [pp, i32, vp, vp, vp]
+    L.scldpc_sw_bp_ring_device.argtypes = [pp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.scldpc_accumulate_run_device.argtypes = [i32, vp, i64, vp, vp]
     L.scldpc_full_bp_lds_bytes.argtypes = [pp]
     L.scldpc_full_bp_lds_bytes.restype = i64

@@ -263,11 +263,42 @@ def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=
     return {"counters": counters, "rows": None, "erased": erased}
 
 
-def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None, classical=False):
+def cn_sockets(p, d_adj16, out=None):
+    """scldpc_cn_sockets_device: the CN -> socket table int16 [T, nk, dc] (uint16 bit patterns) of a 2-byte VN -> CN table."""
+    _require_gpu()
+    T = d_adj16.shape[0]
+    assert d_adj16.is_cuda and d_adj16.dtype == torch.int16 and d_adj16.is_contiguous()
+    if out is None:
+        out = torch.empty((T, p.nk, p.dc), dtype=torch.int16, device=d_adj16.device)
+    check(lib().scldpc_cn_sockets_device(C.byref(p), T, d_adj16.data_ptr(), out.data_ptr(), _stream_ptr(d_adj16.device)))
+    return out
+
+
+def sw_bp(p, d_adj, d_chan, W, max_it, init_it=0, want_erased=False, counters=None, classical=False, ring=None, d_cn_sock=None):
     """decodeBP_SW for a batch resident on the device: square window (BPW:628-912) or, with classical=True, the
-    classical window kept in BPF:627-897 (init_it unused)."""
+    classical window kept in BPF:627-897 (init_it unused).  ring: None = use the window-state-in-LDS kernel (sw_ring.hip)
+    whenever it takes the ensemble (square window, 2-byte tables; the CN -> socket table is built on the fly unless
+    d_cn_sock is given), False = the whole-chain kernel, True = insist on the ring kernel."""
     _require_gpu()
     T = d_adj.shape[0]
+    use_ring = ring
+    if ring is None or ring:
+        ok = (not classical) and _is_adj16(d_adj) and bool(lib().scldpc_sw_bp_ring_supported(C.byref(p), int(W)))
+        if ring and not ok:
+            raise ScldpcError("the ring window kernel takes the square window on 2-byte tables of the (4,8) chain only")
+        use_ring = ok
+    if use_ring:
+        assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+        dev = d_adj.device
+        if counters is None:
+            counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+        erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+        if d_cn_sock is None:
+            d_cn_sock = cn_sockets(p, d_adj)
+        check(lib().scldpc_sw_bp_ring_device(C.byref(p), T, d_adj.data_ptr(), d_cn_sock.data_ptr(), d_chan.data_ptr(), int(W),
+                                             int(max_it), int(init_it), counters.data_ptr(),
+                                             erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+        return {"counters": counters, "erased": erased}
     assert d_adj.is_cuda and d_adj.dtype in (torch.int32, torch.int16) and d_adj.is_contiguous()
     assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
     dev = d_adj.device

@@ -195,6 +195,19 @@ int scldpc_sw_bp_device(const scldpc_code_params *p, int32_t ntrials,
                         int32_t W, int32_t max_it, int32_t init_it,
                         int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
+/* decodeBP_SW, square window, with only the window's state on chip (sw_ring.hip): a ring of W + 2dv - 1 CN positions
+ * (4-bit counts) and W + dv VN positions (S bits) in LDS instead of one word per CN of the whole chain — seven trials per CU
+ * at (L=100, N=2000, W=10), no workspace.  Same counters as scldpc_sw_bp_device.  Takes the 2-byte tables: d_vn_adj16 as
+ * above and d_cn_sock16 uint16 [ntrials][nk][dc] = the sockets of every CN (socket s = dv*t + i is edge i of VN t of
+ * position CNpos - i; 0xFFFF pads chain-end CNs; order within a CN unspecified), which scldpc_cn_sockets_device builds from
+ * any position-structured VN -> CN table (one workgroup per trial and CN position).  *_supported: 1 if (p, W) is taken. */
+int scldpc_sw_bp_ring_supported(const scldpc_code_params *p, int32_t W);
+int scldpc_cn_sockets_device(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                             uint16_t *d_cn_sock16, void *stream);
+int scldpc_sw_bp_ring_device(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                             const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t W, int32_t max_it,
+                             int32_t init_it, int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+
 /* decodeBP_SW, classical window — the variant kept in BPF:627-897 (its call is commented out at BPF:2137-2138):
  * L+dv-1 windows, VNs [posW-ms, posW+W), position posW-ms decided when window posW closes, max_it per window. */
 int scldpc_swc_bp_device(const scldpc_code_params *p, int32_t ntrials,

@@ -91,3 +91,63 @@ def test_small_decoder_on_reference_fixtures(E, name):
     assert (c[:, 2] == g["ee"][:T]).all() and (c[:, 3] == g["bee"][:T]).all() and (c[:, 7] == g["nch"][:T]).all()
     if g.has("erased"):
         assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
+
+
+# ---- square window with only the window's state on chip (sw_ring.hip) ---------------------------------------------------
+@pytest.mark.parametrize("L,N,W,max_it,init_it,eps", [
+    (100, 2000, 10, 20, 0, 0.47), (50, 1000, 20, 6, 60, 0.465), (50, 1000, 10, 20, 0, 0.47), (16, 200, 5, 3, 9, 0.45),
+    (14, 1200, 5, 4, 10, 0.47), (9, 24, 2, 1, 0, 0.5), (10, 10, 4, 3, 7, 0.48), (10, 10, 12, 1000000, 0, 0.42),
+    (30, 400, 1, 2, 3, 0.44), (12, 64, 11, 5, 0, 0.3), (40, 1000, 40, 1000000, 0, 0.47), (20, 100, 3, 50, 0, 0.9)])
+def test_ring_window_decoder_equals_whole_chain_kernel(E, L, N, W, max_it, init_it, eps):
+    """scldpc_sw_bp_ring_device (ring of W+7 CN / W+4 VN positions in LDS, 4-bit counts, CN -> socket table from
+    scldpc_cn_sockets_device) == scldpc_sw_bp_device (one word per CN of the whole chain): every counter incl. the
+    iteration total, NumErasuresP1 and the size-2 stopping-set expurgation, and the VNerased pattern — for windows longer
+    than the chain, W = 1, binding and non-binding caps, V not a multiple of 32, and BASELINE config 4's size."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 48 if N >= 1000 else 160
+    a, ch = E.sample_philox(p, 55, 300, T, eps, adj16=True)
+    old = E.sw_bp(p, a, ch, W, max_it, init_it, want_erased=True, ring=False)
+    new = E.sw_bp(p, a, ch, W, max_it, init_it, want_erased=True, ring=True)
+    torch.cuda.synchronize()
+    assert torch.equal(old["counters"], new["counters"]), (old["counters"][:4], new["counters"][:4])
+    assert torch.equal(old["erased"], new["erased"])
+
+
+def test_cn_socket_table_is_the_inverse_of_the_vn_table(E):
+    import torch
+    for L, N in ((10, 10), (12, 1000), (100, 2000)):
+        p = E.make_params(4, 8, L, N)
+        a, _ = E.sample_philox(p, 9, 0, 2, 0.5, adj16=True)
+        cs = E.cn_sockets(p, a).cpu().numpy().view(np.uint16).astype(np.int64)
+        A = a.cpu().numpy().view(np.uint16).astype(np.int64)
+        for t in range(2):
+            c = cs[t].reshape(L + 3, p.cns_pos, 8)
+            for cpos in (0, 1, 3, L - 1, L, L + 2):
+                valid = c[cpos] != 0xFFFF
+                i, tt = c[cpos] % 4, c[cpos] // 4
+                q = cpos - i
+                assert ((q >= 0) & (q < L))[valid].all()
+                # every listed socket points back at this CN, and the list holds all of them
+                back = A[t].reshape(L, N, 4)[np.clip(q, 0, L - 1), np.clip(tt, 0, N - 1), i]
+                assert (back == np.arange(p.cns_pos)[:, None])[valid].all()
+                assert valid.sum() == sum(N for k in range(4) if 0 <= cpos - k < L)
+
+
+@pytest.mark.parametrize("name", golden_names(variants=("bpw",)))
+def test_ring_window_decoder_on_reference_fixtures(E, name):
+    """The reference's square-window runs (BPW's decodeBP_SW on its own graphs, glibc replay on the fixture's seeds)."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
+    T = min(g.T, 16 if p.n > 10000 else 64)
+    adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])
+    d_a, d_ch = E.to_device(E.global_to_adj16(p, adj), ch)
+    out = E.sw_bp(p, d_a, d_ch, m["W"], m["max_it"], m["init_it"], want_erased=True, ring=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for k, col in (("ne", 0), ("be", 1), ("ee", 2), ("bee", 3), ("p1", 4), ("nch", 7)):
+        assert (c[:, col] == g[k][:T]).all(), (name, k)
+    if g.has("erased"):
+        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
