@@ -147,9 +147,15 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         auto bucket_base = [&](uint32_t b) -> uint32_t {
             return b >= (uint32_t)a.nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
         };
+        // CN = rank / dc, so a bucket whose ranks [g0, g1) lie inside one block of dc ranks gives all its keys the same CN
+        // whatever their order: only the keys of buckets that straddle a multiple of dc are grouped and compared.
+        auto straddles = [&](uint32_t g0, uint32_t g1) {
+            return g1 - g0 > 1u && (a.dc_shift >= 0 ? (g0 >> a.dc_shift) != ((g1 - 1u) >> a.dc_shift)
+                                                    : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
+        };
         for (int s = tid; s < S; s += kThreads) {
-            const uint32_t k = tk[s], g = bucket_base(k >> a.shift) + tslot[s];
-            gkey[g] = k; gidx[g] = (uint16_t)s;
+            const uint32_t k = tk[s], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
+            if (straddles(g0, g1)) { gkey[g0 + tslot[s]] = k; gidx[g0 + tslot[s]] = (uint16_t)s; }
         }
         __syncthreads();
         uint16_t *dst = inter + (size_t)(cpos % dv) * S;
@@ -157,11 +163,12 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             const uint32_t k = tk[s], b = k >> a.shift;
             const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1), self = g0 + tslot[s];
             uint32_t rank = g0;
-            for (uint32_t g = g0; g < g1; g++) {
-                if (g == self) continue;
-                const uint32_t k2 = gkey[g];
-                rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
-            }
+            if (straddles(g0, g1))
+                for (uint32_t g = g0; g < g1; g++) {
+                    if (g == self) continue;
+                    const uint32_t k2 = gkey[g];
+                    rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+                }
             dst[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
         }
         __syncthreads();

@@ -144,3 +144,32 @@ def test_bit_packing_roundtrip():
         b = (rng.rand(3, n) < 0.5).astype(np.uint8)
         w = E.pack_bits(b)
         assert w.shape == (3, (n + 31) // 32) and (E.unpack_bits(w, n) == b).all()
+
+
+def test_second_generation_entry_points_refuse_what_they_do_not_take(L):
+    """Which ensembles the specialised kernels take is a host-side decision (no device needed), and a refusal is an error
+    code with a text, never a silent slow path."""
+    from fl_scaling_sc_ldpc_amd import _lib
+    P = _lib.CodeParams
+    base, wide, long_, big, odd = P(4, 8, 50, 500, 1000), P(4, 8, 50, 512, 1024), P(4, 8, 100, 500, 1000), P(4, 8, 100, 1000, 2000), P(3, 6, 20, 100, 200)
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(base)) == 1 and L.scldpc_full_bp_cn16_supported(C.byref(base)) == 1
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(wide)) == 1                 # 4096 sockets per position: the limit
+    assert L.scldpc_full_bp_cn16_supported(C.byref(long_)) == 0                       # n = 100 000 VNs: ids beyond 16 bits
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(big)) == 0                   # 8000 sockets per position
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(odd)) == 0 and L.scldpc_full_bp_cn16_supported(C.byref(odd)) == 0
+    assert L.scldpc_sample_philox_device_cn16(C.byref(big), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -2
+    assert b"4096" in L.scldpc_last_error()
+    assert L.scldpc_full_bp_fixpoint_device_cn16(C.byref(long_), 4, None, None, None, 1, None, None, None) == -2
+    assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 0, 0.5, 0, None, None, None, None, None) == 0      # empty batch
+    assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -1     # null buffers
+    assert L.scldpc_full_bp_fixpoint_device_cn16(C.byref(base), 4, None, None, None, 1, None, None, None) == -1
+    # window decoder with the window's state in LDS: (4,8) chains with 16-bit sockets, any window that fits
+    assert L.scldpc_sw_bp_ring_supported(C.byref(big), 10) == 1 and L.scldpc_sw_bp_ring_supported(C.byref(base), 20) == 1
+    assert L.scldpc_sw_bp_ring_supported(C.byref(odd), 5) == 0 and L.scldpc_sw_bp_ring_supported(C.byref(base), 0) == 0
+    assert L.scldpc_sw_bp_ring_supported(C.byref(P(4, 8, 400, 5000, 10000)), 300) == 0   # 307 positions of counts: beyond the LDS
+    assert L.scldpc_sw_bp_ring_device(C.byref(odd), 4, None, None, None, 5, 3, 0, None, None, None) == -1             # null buffers first
+    assert L.scldpc_cn_sockets_device(C.byref(base), 0, None, None, None) == 0
+    assert L.scldpc_cn_sockets_device(C.byref(base), 2, None, None, None) == -1
+    # same-input streaming: the inputs must cover what the call will generate
+    assert L.scldpc_stream_run_device_inputs(C.byref(base), 1, 20, 0, None, 10, None, None, None, None, None, 30, 0, None) == -1
+    assert L.scldpc_stream_glibc_inputs_host(C.byref(base), 1, 0.5, 0, None, -1, None, None) == -1
