@@ -82,3 +82,44 @@ def test_two_streams_with_their_own_workspaces_do_not_interfere():
     rc = E.lib().scldpc_full_bp_device_adj16(C.byref(p), T, a1.data_ptr(), c1.data_ptr(), 0, 1, cnt.data_ptr(), None, 0, None,
                                              small.data_ptr(), need - 256, None)
     assert rc == -1 and b"workspace" in E.lib().scldpc_last_error()
+
+
+def test_entry_points_can_be_captured_into_a_graph():
+    """include/scldpc.h: device entry points only enqueue work — no allocation, no synchronisation, no hidden state — so
+    a whole step (sample -> decode -> accumulate) can be captured into a hipGraph and replayed: the replays give what
+    eager calls give, and a replay after new inputs were written into the same buffers sees them."""
+    require_gpu()
+    import torch
+    from fl_scaling_sc_ldpc_amd import engine as E
+    p = E.make_params(4, 8, 50, 1000)
+    T = 512
+    a16 = torch.empty((T, p.n, 4), dtype=torch.int16, device="cuda")
+    cn16 = torch.empty((T, p.nk, 8), dtype=torch.int16, device="cuda")
+    ch = torch.empty((T, p.nw), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((T, E.NCOUNTERS), dtype=torch.int32, device="cuda")
+    run = E.new_run()
+
+    def step():
+        E.sample_philox_cn16(p, 99, 0, T, 0.48, out=(a16, cn16, ch))
+        E.full_bp_fixpoint_cn16(p, a16, cn16, ch, counters=cnt)
+        E.accumulate_run(cnt, run, 0)
+
+    step()                                                  # eager reference (also loads the code objects)
+    torch.cuda.synchronize()
+    want_cnt, want_run = cnt.clone(), run.clone()
+    run.zero_(); cnt.zero_()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        step()
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    run.zero_(); cnt.zero_()
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    keep = [0, 1, 2, 3, 4, 6, 7]
+    assert torch.equal(cnt[:, keep], want_cnt[:, keep])
+    assert torch.equal(run[:8], 2 * want_run[:8])           # two replays accumulated twice
