@@ -154,3 +154,109 @@ def test_the_model_has_teeth():
         except IndexError:
             bad += 1                                    # a garbage fold decoded to a VN outside the graph
     assert bad > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The count-only protocol of fl_scaling_sc_ldpc_amd/csrc/full_bp_small.hip (4 bits per CN, no fold): a CN whose count is one
+# reads its neighbour list and takes the neighbour whose U bit is still set.
+#     entry c popped from the worker's queue
+#     1. for each of c's neighbours (one LDS read each, at different times): remember the last one whose U bit is set
+#     2. claim: test-and-clear U[j]; give up if it was clear (or if no neighbour had its bit set)
+#     3. for each edge i: old = cnt[row[i]]; cnt[row[i]] -= 1    (4 separate atomic decrements, each returns old)
+#        if old == 2: push row[i] to the own queue
+# Safe because the claim comes BEFORE the decrements: a neighbour that is counted but no longer erased has its bit clear.
+# ------------------------------------------------------------------------------------------------------------------------
+def count_worker(queue, st, claim_first=True):
+    adj, nbrs = st["adj"], st["nbrs"]
+    while queue:
+        c = queue.pop(0)
+        j = -1
+        for v in nbrs[c]:
+            yield                                      # --- one read of the bitmap
+            if st["U"][v]:
+                j = v
+        if j < 0:
+            continue
+        row = adj[j]
+        if claim_first:
+            yield                                      # --- claim (atomic test-and-clear)
+            if not st["U"][j]:
+                continue
+            st["U"][j] = False
+            st["released"].append(j)
+        for i in range(4):
+            yield                                      # --- one atomic decrement, returns the old count
+            old = st["cnt"][row[i]]
+            st["cnt"][row[i]] -= 1
+            if old == 2:
+                queue.append(int(row[i]))
+        if not claim_first:                            # (negative control: the bit is cleared only after the decrements)
+            yield
+            if st["U"][j]:
+                st["U"][j] = False
+            st["released"].append(j)
+
+
+def _count_state(adj, erased, ncn):
+    cnt = np.zeros(ncn, dtype=np.int64)
+    nbrs = [[] for _ in range(ncn)]
+    for j in range(adj.shape[0]):
+        for i in range(4):
+            nbrs[adj[j, i]].append(j)
+    for j in np.flatnonzero(erased):
+        cnt[adj[j]] += 1
+    return dict(adj=adj, nbrs=nbrs, U=erased.copy(), released=[], cnt=cnt)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_count_only_protocol_reaches_the_closure_under_any_interleaving(seed):
+    rs = np.random.RandomState(500 + seed)
+    L, V = int(rs.randint(4, 9)), int(rs.choice([8, 12, 16]))
+    adj, C, ncn = make_graph(rs, L, V)
+    eps = float(rs.choice([0.3, 0.42, 0.47, 0.5, 0.6]))
+    erased = rs.rand(L * V) <= eps
+    want = closure(adj, erased, ncn)
+    for trial in range(6):
+        st = _count_state(adj, erased, ncn)
+        nworkers = int(rs.randint(1, 7))
+        queues = [[] for _ in range(nworkers)]
+        for k, c in enumerate(np.flatnonzero(st["cnt"] == 1)):
+            queues[k % nworkers].append(int(c))
+        live = [count_worker(queues[w], st) for w in range(nworkers)]
+        while live:
+            g = live[rs.randint(len(live))]
+            try:
+                for _ in range(int(rs.randint(1, 6))):
+                    next(g)
+            except StopIteration:
+                live.remove(g)
+        assert len(st["released"]) == len(set(st["released"])), "a VN was released twice"
+        assert (st["U"] == want).all(), (seed, trial, int(st["U"].sum()), int(want.sum()))
+        cnt = np.zeros(ncn, dtype=np.int64)
+        for j in np.flatnonzero(st["U"]):
+            cnt[adj[j]] += 1
+        assert (cnt == st["cnt"]).all() and (st["cnt"] >= 0).all()
+
+
+def test_the_count_only_model_has_teeth():
+    """Negative control: clearing the U bit only AFTER the decrements lets two CNs release the same VN (its counts go
+    negative / it is released twice) under some interleaving."""
+    bad = 0
+    for seed in range(60):
+        rs = np.random.RandomState(2000 + seed)
+        adj, C, ncn = make_graph(rs, 6, 12)
+        erased = rs.rand(6 * 12) <= 0.47
+        want = closure(adj, erased, ncn)
+        st = _count_state(adj, erased, ncn)
+        queues = [[] for _ in range(5)]
+        for k, c in enumerate(np.flatnonzero(st["cnt"] == 1)):
+            queues[k % 5].append(int(c))
+        live = [count_worker(queues[w], st, claim_first=False) for w in range(5)]
+        while live:
+            g = live[rs.randint(len(live))]
+            try:
+                next(g)
+            except StopIteration:
+                live.remove(g)
+        bad += (len(st["released"]) != len(set(st["released"]))) or (st["cnt"] < 0).any() or not (st["U"] == want).all()
+    assert bad > 0
