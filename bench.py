@@ -301,7 +301,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
                                    "traffic": tr_dec["hbm_bytes"] if tr_dec else None,
                                    "traffic_raw": tr_dec["hbm_bytes_raw"] if tr_dec else None,
                                    "read_requests_per_s": (tr_dec["rdreq"] / (ms_bp * 1e-3)) if tr_dec and tr_dec.get("rdreq") else None,
-                                   "bound": "HBM read-request rate (one 128-B request per row gather)" if gen2 else
+                                   "bound": "HBM at line granularity (one 128-B line per 8- or 16-byte row gather)" if gen2 else
                                             "latency of ~230 dependent levels"}}}
     if a.flooding:
         # literal flooding moves 8*E*(1 + I_t) bytes for a trial of I_t iterations (secondary figure)

@@ -38,6 +38,20 @@ __global__ void calib_gather(const T *p, uint32_t nrows, int count, uint32_t *si
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// every lane reads `count` random ALIGNED 128-byte rows in full (8 x 16 B): one L2 line each — does the L2 ask the
+// fabric for it in one request or in two 64-byte ones?
+__global__ void calib_gather_line(const uint4 *p, uint32_t nlines, int count, uint32_t *sink)
+{
+    uint32_t acc = 0, h = mix(blockIdx.x * 1024u + threadIdx.x + 77u);
+    for (int k = 0; k < count; k++) {
+        h = mix(h + 0x9E3779B9u);
+        const uint4 *row = p + (size_t)(h % nlines) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint4 v = row[i]; acc ^= v.x ^ v.w; }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 __global__ void calib_store8(uint2 *p, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -61,6 +75,8 @@ int main()
     hipLaunchKernelGGL(calib_gather<uint2>, dim3(blocks), dim3(threads), 0, 0, (const uint2 *)buf, (uint32_t)(bytes / 8 - 1), count, sink);
     // (c) as many random 16-byte rows = 2 GiB of requested bytes
     hipLaunchKernelGGL(calib_gather<uint4>, dim3(blocks), dim3(threads), 0, 0, (const uint4 *)buf, (uint32_t)(bytes / 16 - 1), count, sink);
+    // (c') 2048*256*32 = 16 777 216 random full 128-byte lines = 2 GiB
+    hipLaunchKernelGGL(calib_gather_line, dim3(blocks), dim3(threads), 0, 0, (const uint4 *)buf, (uint32_t)(bytes / 128 - 1), 32, sink);
     // (d) 4 GiB stored at 8 B per lane
     hipLaunchKernelGGL(calib_store8, dim3(blocks), dim3(threads), 0, 0, (uint2 *)buf, ((size_t)4 << 30) / 8);
     CHECK(hipDeviceSynchronize());
