@@ -139,6 +139,11 @@ class Simulator:
         self.d_adj = torch.empty((batch, p.n, p.dv), dtype=adj_dtype, device=self.device)
         self.d_ch = torch.empty((batch, p.nw), dtype=torch.int32, device=self.device)
         self.d_cnt = torch.empty((batch, NCOUNTERS), dtype=torch.int32, device=self.device)
+        # unlimited full BP without iteration statistics on the BASELINE ensemble family: the second-generation pair
+        # (sampler_v2 + the 4-bits-per-CN decoder) needs the CN -> VN table next to the VN -> CN one
+        self.gen2 = (self.rng == "philox" and self.decoder == "full" and self.schedule == "fixpoint" and self.rows_cap == 0
+                     and (self.max_it <= 0 or self.max_it >= 1000000) and E.cn16_supported(p))
+        self.d_cn = torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device) if self.gen2 else None
 
     def _accumulate(self, allcnt, run, stop_frame_err):
         return E.accumulate_run(allcnt, run, stop_frame_err)
@@ -151,13 +156,18 @@ class Simulator:
         adj, ch, cnt = self.d_adj[:nb], self.d_ch[:nb], self.d_cnt[:nb]
         if self.decoder == "sw":
             return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt)
+        if self.gen2 and not want_rows:
+            return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt)
         if self.schedule == "fixpoint" and not want_rows and (self.max_it <= 0 or self.max_it >= 1000000):
             return E.full_bp_fixpoint(self.p, adj, ch, is_term=self.is_term, counters=cnt)    # no iteration counts
         return E.full_bp(self.p, adj, ch, max_it=self.max_it, is_term=self.is_term,
                          rows_cap=self.rows_cap if want_rows else 0, counters=cnt)
 
     def fill_batch(self, sim, eps, frame0, nb):
-        if self.rng == "philox":
+        if self.rng == "philox" and self.gen2:
+            E.sample_philox_cn16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+                                 out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
+        elif self.rng == "philox":
             E.sample_philox(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
                             out=(self.d_adj[:nb], self.d_ch[:nb]))
         else:
