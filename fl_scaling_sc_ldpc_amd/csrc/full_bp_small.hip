@@ -5,8 +5,9 @@
 // the latency of its ~230 dependent levels.  Here a CN keeps ONLY the count (a nibble): when it drops to
 // one, its dc neighbours are read from the CN -> VN table the second-generation sampler emits (sampler_v2.hip) and the
 // one neighbour whose bit in the erased-VN bitmap U is still set is the one to resolve.  A trial needs 13 + 6 KiB of
-// state + queues = 26 KiB, a 256-thread workgroup decodes it, and six trials share a CU: three times the trials in
-// flight for one more dependent gather per level.
+// state + queues = 23 KiB, a 256-thread workgroup decodes it, and seven trials share a CU: 3.5 times the trials in
+// flight for one more dependent gather per level (measured A/B of workgroup sizes 64 … 512, five to eight trials per
+// CU and the switch-over width: DESIGN.md §5).
 //
 // Safe without a barrier per level because every release claims its VN in U (atomic test-and-clear) BEFORE it decrements
 // the VN's CNs: whoever sees a CN's count reach one (its decrement returned two, or a scan read one) sees at most one
@@ -330,16 +331,11 @@ int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_c
     return 0;
 }
 
-int g_block = 256, g_per_cu = 7, g_kswitch = 128;        // tuning knobs (tools/ab_v2.py): scldpc_debug_small_cfg
+constexpr int kBlockSmall = 256;        // threads per trial
+constexpr int kPerCu = 7;               // workgroups per CU the LDS carve aims at (SGPRs <= 96, VGPRs <= 72)
+constexpr int kSwitchWidth = 128;       // frontier entries below which the waves go private
 
 }  // namespace
-
-extern "C" int scldpc_debug_small_cfg(int block, int per_cu, int kswitch)
-{
-    if (block != 64 && block != 128 && block != 256 && block != 512) return -1;
-    g_block = block; g_per_cu = per_cu; g_kswitch = kswitch;
-    return 0;
-}
 
 // 1 when scldpc_full_bp_fixpoint_device_cn16 takes this ensemble
 extern "C" int scldpc_full_bp_cn16_supported(const scldpc_code_params *p)
@@ -365,7 +361,7 @@ extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, 
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
     if (ntrials == 0) return SCLDPC_OK;
     SmArgs a{};
-    int per_cu = g_per_cu;                                               // workgroups per CU the LDS carve aims at
+    int per_cu = kPerCu;                                               // workgroups per CU the LDS carve aims at
     while (per_cu > 1 && make_args(p, is_term, &a, per_cu) != 0) per_cu--;
     if (make_args(p, is_term, &a, per_cu) != 0)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the CN counts and VN bits do not fit the LDS", who);
@@ -373,13 +369,12 @@ extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, 
     scldpc::magic_of(p->cns_pos, a.nk, &a.magic_c);
     a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
     a.counters = d_counters; a.erased_out = d_erased_bits;
-    a.kswitch = g_kswitch;
-    void (*kern)(const SmArgs) = g_block == 64 ? full_bp_small_kernel<64> : g_block == 128 ? full_bp_small_kernel<128>
-                                 : g_block == 512 ? full_bp_small_kernel<512> : full_bp_small_kernel<256>;
+    a.kswitch = kSwitchWidth;
+    void (*kern)(const SmArgs) = full_bp_small_kernel<kBlockSmall>;
     const size_t lds_bytes = 4u * (size_t)a.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(g_block), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlockSmall), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
 }
