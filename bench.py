@@ -414,6 +414,10 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
     d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev)
     d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
     d_cnt = torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev)
+    gen2 = not a.gen1
+    if gen2 and not E.sock16_supported(p):
+        raise SystemExit("bench.py: the second-generation sampler does not take this ensemble")
+    d_cs = torch.empty((B, p.nk, p.dc), dtype=torch.int16, device=dev) if gen2 else None
     run = E.new_run(dev)
     ev = _events(a.steps, 3)
 
@@ -421,10 +425,13 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
         trial0 = (k * world + rank) * B
         if e:
             e[0].record()
-        E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj, d_ch))
+        if gen2:                                        # the sampler emits the CN -> socket table with the code
+            E.sample_philox_sock16(p, SEED, trial0, B, EPS, out=(d_adj, d_cs, d_ch))
+        else:                                           # first generation: sampler.hip, then a cn_sockets pass inside sw_bp
+            E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj, d_ch))
         if e:
             e[1].record()
-        E.sw_bp(p, d_adj, d_ch, W, IT, 0, counters=d_cnt)
+        E.sw_bp(p, d_adj, d_ch, W, IT, 0, counters=d_cnt, d_cn_sock=d_cs)
         if e:
             e[2].record()
         E.accumulate_run(d_cnt, run, 0)
@@ -459,9 +466,10 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u32", "data": "synthetic",
            "config": {"workload": f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} decodeBP_SW W={W} I_max={IT} I_init={IT}",
-                      "trials_per_gpu_per_step": B, "step": "device sample -> CN->socket table -> decodeBP_SW (window state in LDS) -> plr_computation",
+                      "trials_per_gpu_per_step": B, "step": ("device sample (code + CN->socket table) -> decodeBP_SW (window state in LDS) -> plr_computation" if gen2 else
+                               "device sample -> CN->socket table -> decodeBP_SW (window state in LDS) -> plr_computation"),
                       "parallelism": f"trial-sharded x{world} (the eps grid shards by point in bp_decoding.py)"},
-           "roofline": {"bound": "hbm", "kernel": "sw_ring_kernel (+ cn_sockets_kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "sw_ring_kernel" if gen2 else "sw_ring_kernel (+ cn_sockets_kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_trial": share, "ms_per_launch": ms_w,
                         "literal_flooding": {"bytes": "8*E_w*sum I, E_w = W*N*dv", "sum_iterations": r["iterations"],
                                              "equivalent_GBs": lit, "x_peak": lit / HBM_PEAK_GBS},

@@ -33,6 +33,7 @@ EXPORTS = (
     "scldpc_swc_bp_device", "scldpc_swc_bp_device_adj16", "scldpc_sample_philox_ensemble_device",
     "scldpc_full_bp_fixpoint_device", "scldpc_full_bp_fixpoint_device_adj16",
     "scldpc_sample_philox_cn16_supported", "scldpc_sample_philox_device_cn16",
+    "scldpc_sample_philox_sock16_supported", "scldpc_sample_philox_device_sock16",
     "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16",
     "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
     "scldpc_sw_bp_ring_supported", "scldpc_cn_sockets_device", "scldpc_sw_bp_ring_device",
@@ -100,6 +101,8 @@ def lib():
     L.scldpc_sample_philox_cn16_supported.argtypes = [pp]
     L.scldpc_full_bp_cn16_supported.argtypes = [pp]
     L.scldpc_sample_philox_device_cn16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
+    L.scldpc_sample_philox_sock16_supported.argtypes = [pp]
+    L.scldpc_sample_philox_device_sock16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, u64, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp, u64, vp]

@@ -143,7 +143,11 @@ class Simulator:
         # (sampler_v2 + the 4-bits-per-CN decoder) needs the CN -> VN table next to the VN -> CN one
         self.gen2 = (self.rng == "philox" and self.decoder == "full" and self.schedule == "fixpoint" and self.rows_cap == 0
                      and (self.max_it <= 0 or self.max_it >= 1000000) and E.cn16_supported(p))
-        self.d_cn = torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device) if self.gen2 else None
+        # square-window decoding with the window's state in LDS reads a CN -> socket table: sampled with the code where the
+        # second-generation sampler takes the ensemble (else E.sw_bp builds it in a pass of its own)
+        self.ring2 = (self.rng == "philox" and self.decoder == "sw" and adj_dtype == torch.int16
+                      and E.sock16_supported(p) and E.sw_ring_supported(p, self.W))
+        self.d_cn = torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device) if (self.gen2 or self.ring2) else None
 
     def _accumulate(self, allcnt, run, stop_frame_err):
         return E.accumulate_run(allcnt, run, stop_frame_err)
@@ -155,7 +159,8 @@ class Simulator:
     def decode_batch(self, nb, want_rows=False):
         adj, ch, cnt = self.d_adj[:nb], self.d_ch[:nb], self.d_cnt[:nb]
         if self.decoder == "sw":
-            return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt)
+            return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt,
+                           d_cn_sock=self.d_cn[:nb] if self.ring2 else None)
         if self.gen2 and not want_rows:
             return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt)
         if self.schedule == "fixpoint" and not want_rows and (self.max_it <= 0 or self.max_it >= 1000000):
@@ -167,6 +172,9 @@ class Simulator:
         if self.rng == "philox" and self.gen2:
             E.sample_philox_cn16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
                                  out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
+        elif self.rng == "philox" and self.ring2:
+            E.sample_philox_sock16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+                                   out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox":
             E.sample_philox(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
                             out=(self.d_adj[:nb], self.d_ch[:nb]))

@@ -26,7 +26,7 @@ using scldpc_dev::wave_inclusive_scan;
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxDoped = 32;
-constexpr int kWorkCap = 512;           // keys of buckets that span two CNs, per position (expected: 0.03 * S <= 123)
+constexpr int kWorkCap = 1024;          // keys of buckets that span two CNs, per position (expected: 0.03 * S <= 250)
 
 struct S2Args {
     int L, cns_pos, vns_pos, n, S, D, nb, shift, sbits, nw;
@@ -41,16 +41,19 @@ struct S2Args {
     uint32_t *chan;
 };
 
-// ROWS = 64-counter rows of the histogram each wave scans (nb / 1024)
-template <int ROWS>
+// KMAX = Philox calls (4 sockets each) per thread and position: 1 up to 4096 sockets per position, 2 up to 8192
+// ROWS = histogram words per thread (nb / 1024)
+// CNMODE: what the rank-ordered stage holds — 0 nothing, 1 the sockets' VNs (global VN index, scldpc_sample_philox_device_cn16),
+//         2 the sockets themselves (s = dv*t + i: the table scldpc_sw_bp_ring_device reads; any n)
+template <int KMAX, int ROWS, int CNMODE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_v2_kernel(const S2Args a)
 {
-    constexpr int DV = 4, DC_SHIFT = 3;
+    constexpr int DV = 4, DC_SHIFT = 3, E = 4 * KMAX;
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                               // nb words of four nibble-wide bucket counters
     uint32_t *gpk = lds + a.off_gpk;                                    // S words: packed keys of straddling buckets
     uint16_t *win = reinterpret_cast<uint16_t *>(lds + a.off_win);      // ring of dv x S CN-local ids
-    uint16_t *stage = reinterpret_cast<uint16_t *>(lds + a.off_stage);  // the S sockets' VNs in rank order (CN -> VNs)
+    uint16_t *stage = reinterpret_cast<uint16_t *>(lds + a.off_stage);  // the S sockets (or their VNs) in rank order
     uint32_t *wsum = lds + a.off_wsum;                                  // 16 wave totals + the worklist counter
     uint32_t *wl = wsum + 32;                                           // worklist: 2 words per key of a straddling bucket
 
@@ -61,14 +64,41 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     const int ncalls = S >> 2;                                          // S % 4 == 0 (checked on the host)
     const int kshift = a.shift - 2;                                     // key >> kshift = fine bucket
     const uint32_t lowmask = (1u << kshift) - 1u;
-    const bool mine4 = tid < ncalls;                                    // this thread owns sockets 4*tid .. 4*tid+3
+    bool own[KMAX];                                                     // call k of this thread: sockets 4*(tid + 1024 k) .. +3
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) own[k] = tid + k * kThreads < ncalls;
+    auto sock = [&](int e) { return (uint32_t)((tid + (e >> 2) * kThreads) * 4 + (e & 3)); };
+    // what the stage holds for socket sck = 4*t + u at CN position p: edge u of VN t of position p - u (BPF:1712)
+    auto stage_entry = [&](int p, uint32_t sck) -> uint16_t {
+        const int u = (int)(sck & 3u), t = (int)(sck >> 2);
+        if ((unsigned)(p - u) >= (unsigned)a.L) return (uint16_t)0xFFFFu;
+        return CNMODE == 1 ? (uint16_t)((p - u) * a.vns_pos + t) : (uint16_t)sck;
+    };
 
     // hist word = [exclusive prefix:16 | n3:4 | n2:4 | n1:4 | n0:4]: four nibble-wide bucket counters in the low half
     // (the atomic's return value is the key's arrival slot), the scan's prefix ORed into the high half.  Thread t owns
-    // words t*ROWS .. t*ROWS+ROWS-1 (one wide LDS access).
+    // words t*ROWS .. t*ROWS+ROWS-1 (wide LDS accesses).
     auto nib_sum = [](uint32_t x) {                                     // sum of the four nibbles of the low half
         const uint32_t v = (x & 0x0F0Fu) + ((x >> 4) & 0x0F0Fu);
         return (v + (v >> 8)) & 0xFFu;
+    };
+    auto load_words = [&](uint32_t (&x)[ROWS]) {
+        if constexpr (ROWS % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r < ROWS / 4; r++) {
+                const uint4 q = reinterpret_cast<const uint4 *>(hist)[tid * (ROWS / 4) + r];
+                x[4 * r] = q.x; x[4 * r + 1] = q.y; x[4 * r + 2] = q.z; x[4 * r + 3] = q.w;
+            }
+        } else if constexpr (ROWS == 2) { const uint2 q = reinterpret_cast<const uint2 *>(hist)[tid]; x[0] = q.x; x[1] = q.y; }
+        else x[0] = hist[tid];
+    };
+    auto store_words = [&](const uint32_t (&x)[ROWS]) {
+        if constexpr (ROWS % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r < ROWS / 4; r++)
+                reinterpret_cast<uint4 *>(hist)[tid * (ROWS / 4) + r] = make_uint4(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3]);
+        } else if constexpr (ROWS == 2) reinterpret_cast<uint2 *>(hist)[tid] = make_uint2(x[0], x[1]);
+        else hist[tid] = x[0];
     };
     STAMP_DECL
     for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
@@ -76,22 +106,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     __syncthreads();
     // The keys of position p+1 are drawn (pure VALU) while the few worklist lanes of position p chase their bucket mates
     // through the LDS: nxt[] carries them across the barrier.
-    uint32_t nxt[4] = {0, 0, 0, 0};
-    if (mine4) philox4x32_10((uint32_t)tid, 0u, t_lo, t_hi, a.seed_lo, a.seed_hi, nxt);
+    uint32_t nxt[E];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        uint32_t r[4] = {0, 0, 0, 0};
+        if (own[k]) philox4x32_10((uint32_t)(tid + k * kThreads), 0u, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+        for (int u = 0; u < 4; u++) nxt[4 * k + u] = r[u];
+    }
     for (int p = 0; p < a.D; p++) {
         STAMP(0);
         // ---- bucket histogram of this position's keys
-        uint32_t key[4], slot[4], crowded = 0;
-        {
+        uint32_t key[E], slot[E], crowded = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                key[u] = nxt[u];
-                slot[u] = 0;
-                if (mine4) {
-                    const uint32_t b = key[u] >> kshift, sh = (b & 3u) * 4u;
-                    slot[u] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFu;
-                    crowded = max(crowded, slot[u]);
-                }
+        for (int e = 0; e < E; e++) {
+            key[e] = nxt[e];
+            slot[e] = 0;
+            if (own[e >> 2]) {
+                const uint32_t b = key[e] >> kshift, sh = (b & 3u) * 4u;
+                slot[e] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFu;
+                crowded = max(crowded, slot[e]);
             }
         }
         if (crowded >= 15u) __builtin_trap();                           // a bucket count must fit its nibble (never happens:
@@ -102,9 +136,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         //      (DPP), the 16 wave totals meet in wsum; the global prefix goes into the words' high halves
         {
             uint32_t x[ROWS], v[ROWS], tot = 0;
-            if constexpr (ROWS == 4) { const uint4 q = reinterpret_cast<const uint4 *>(hist)[tid]; x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
-            else if constexpr (ROWS == 2) { const uint2 q = reinterpret_cast<const uint2 *>(hist)[tid]; x[0] = q.x; x[1] = q.y; }
-            else x[0] = hist[tid];
+            load_words(x);
 #pragma unroll
             for (int r = 0; r < ROWS; r++) { v[r] = nib_sum(x[r]); tot += v[r]; }
             const uint32_t inc = wave_inclusive_scan(tot);
@@ -115,73 +147,84 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
             uint32_t pre = inc - tot + (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);
 #pragma unroll
             for (int r = 0; r < ROWS; r++) { x[r] |= pre << 16; pre += v[r]; }
-            if constexpr (ROWS == 4) reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(x[0], x[1], x[2], x[3]);
-            else if constexpr (ROWS == 2) reinterpret_cast<uint2 *>(hist)[tid] = make_uint2(x[0], x[1]);
-            else hist[tid] = x[0];
+            store_words(x);
         }
         __syncthreads();
         STAMP(2);
 
         // ---- classify: every key gets rank g0 + arrival slot — any bijection onto its bucket's ranks gives the right CN
-        //      (g0 / dc) when the bucket lies inside one block of dc ranks.  CN ids go into the ring, VNs into the
+        //      (g0 / dc) when the bucket lies inside one block of dc ranks.  CN ids go into the ring, sockets into the
         //      rank-ordered stage.  Keys of buckets that span two CNs (3 %) are also put on a worklist for their true rank.
         uint16_t *wp = win + (size_t)(p & 3) * S;
         {
-            uint32_t h[4], rk[4], g0a[4], cnta[4], smask = 0;
+            uint32_t h[E], rk[E], g0a[E], cnta[E], smask = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) h[u] = hist[mine4 ? (key[u] >> kshift) >> 2 : 0u];
+            for (int e = 0; e < E; e++) h[e] = hist[own[e >> 2] ? (key[e] >> kshift) >> 2 : 0u];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t k4 = ((key[u] >> kshift) & 3u) * 4u, x = h[u];
+            for (int e = 0; e < E; e++) {
+                const uint32_t k4 = ((key[e] >> kshift) & 3u) * 4u, x = h[e];
                 const uint32_t below = x & ((1u << k4) - 1u);            // the counters of the word's lower buckets
-                g0a[u] = (x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu);
-                cnta[u] = (x >> k4) & 0xFu;
-                rk[u] = g0a[u] + slot[u];
-                if (mine4 && ((g0a[u] + cnta[u] - 1u) >> DC_SHIFT) != (g0a[u] >> DC_SHIFT)) smask |= 1u << u;
+                g0a[e] = (x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu);
+                cnta[e] = (x >> k4) & 0xFu;
+                rk[e] = g0a[e] + slot[e];
+                if (own[e >> 2] && ((g0a[e] + cnta[e] - 1u) >> DC_SHIFT) != (g0a[e] >> DC_SHIFT)) smask |= 1u << e;
             }
             while (smask) {                                             // rare (3 % of the keys): one short divergent loop
-                const uint32_t u = (uint32_t)__ffs((int)smask) - 1u;
+                const uint32_t e = (uint32_t)__ffs((int)smask) - 1u;
                 smask &= smask - 1u;
-                const uint32_t ky = u == 0 ? key[0] : u == 1 ? key[1] : u == 2 ? key[2] : key[3];
-                const uint32_t sl = u == 0 ? slot[0] : u == 1 ? slot[1] : u == 2 ? slot[2] : slot[3];
-                const uint32_t g0 = u == 0 ? g0a[0] : u == 1 ? g0a[1] : u == 2 ? g0a[2] : g0a[3];
-                const uint32_t cnt = u == 0 ? cnta[0] : u == 1 ? cnta[1] : u == 2 ? cnta[2] : cnta[3];
-                const uint32_t pk = ((ky & lowmask) << a.sbits) | ((uint32_t)tid * 4u + u);
-                gpk[g0 + sl] = pk;
-                const int e = atomicAdd(reinterpret_cast<int *>(&wsum[kWaves]), 1);
-                if (e < kWorkCap) { wl[2 * e] = g0 | (cnt << 16) | (sl << 20); wl[2 * e + 1] = pk; }
-            }
-            if (mine4) {
+                uint32_t ky = key[0], sl = slot[0], g0 = g0a[0], cnt = cnta[0];
 #pragma unroll
-                for (int u = 0; u < 4; u++)                             // socket 4*tid + u is edge u of VN tid of position p - u (BPF:1712)
-                    stage[rk[u]] = (unsigned)(p - u) < (unsigned)a.L ? (uint16_t)((p - u) * a.vns_pos + tid) : (uint16_t)0xFFFFu;
+                for (int f = 1; f < E; f++)
+                    if (e == (uint32_t)f) { ky = key[f]; sl = slot[f]; g0 = g0a[f]; cnt = cnta[f]; }
+                const uint32_t pk = ((ky & lowmask) << a.sbits) | (uint32_t)((tid + (int)(e >> 2) * kThreads) * 4 + (int)(e & 3u));
+                gpk[g0 + sl] = pk;
+                const int w = atomicAdd(reinterpret_cast<int *>(&wsum[kWaves]), 1);
+                if (w < kWorkCap) { wl[2 * w] = g0 | (cnt << 16) | (sl << 20); wl[2 * w + 1] = pk; }
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                if (!own[k]) continue;
+                if constexpr (CNMODE != 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) stage[rk[4 * k + u]] = stage_entry(p, sock(4 * k + u));
+                }
                 uint2 v;
-                v.x = (rk[0] >> DC_SHIFT) | ((rk[1] >> DC_SHIFT) << 16); v.y = (rk[2] >> DC_SHIFT) | ((rk[3] >> DC_SHIFT) << 16);
-                *reinterpret_cast<uint2 *>(wp + tid * 4) = v;
+                v.x = (rk[4 * k] >> DC_SHIFT) | ((rk[4 * k + 1] >> DC_SHIFT) << 16);
+                v.y = (rk[4 * k + 2] >> DC_SHIFT) | ((rk[4 * k + 3] >> DC_SHIFT) << 16);
+                *reinterpret_cast<uint2 *>(wp + (tid + k * kThreads) * 4) = v;
             }
         }
         __syncthreads();
         STAMP(3);
 
         // ---- the worklist: true rank among the bucket mates; counters cleared for the next position
-        if constexpr (ROWS == 4) reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(0, 0, 0, 0);
-        else if constexpr (ROWS == 2) reinterpret_cast<uint2 *>(hist)[tid] = make_uint2(0, 0);
-        else hist[tid] = 0;
         {
+            uint32_t z[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) z[r] = 0;
+            store_words(z);
             const int nwork = (int)wsum[kWaves];
-            if (nwork > kWorkCap) __builtin_trap();                     // 3 % of S on average (<= 123 keys); the list holds 512
-            for (int e = tid; e < nwork; e += kThreads) {
-                const uint32_t ea = wl[2 * e], pk = wl[2 * e + 1];
+            if (nwork > kWorkCap) __builtin_trap();                     // 3 % of S on average (<= 250 keys); the list holds 1024
+            for (int w = tid; w < nwork; w += kThreads) {
+                const uint32_t ea = wl[2 * w], pk = wl[2 * w + 1];
                 const uint32_t g0 = ea & 0xFFFFu, cnt = (ea >> 16) & 0xFu, sl = ea >> 20;
                 uint32_t r = g0;
                 for (uint32_t m = 0; m < cnt; m++)
                     if (m != sl) r += gpk[g0 + m] < pk;
-                const uint32_t sck = pk & ((1u << a.sbits) - 1u), t = sck >> 2, u = sck & 3u;
-                stage[r] = (unsigned)(p - (int)u) < (unsigned)a.L ? (uint16_t)((p - (int)u) * a.vns_pos + (int)t) : (uint16_t)0xFFFFu;
+                const uint32_t sck = pk & ((1u << a.sbits) - 1u);
+                if constexpr (CNMODE != 0) stage[r] = stage_entry(p, sck);
                 wp[sck] = (uint16_t)(r >> DC_SHIFT);
             }
         }
-        if (mine4 && p + 1 < a.D) philox4x32_10((uint32_t)tid, (uint32_t)(p + 1), t_lo, t_hi, a.seed_lo, a.seed_hi, nxt);
+        if (p + 1 < a.D) {
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                uint32_t r[4] = {0, 0, 0, 0};
+                if (own[k]) philox4x32_10((uint32_t)(tid + k * kThreads), (uint32_t)(p + 1), t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+                for (int u = 0; u < 4; u++) nxt[4 * k + u] = r[u];
+            }
+        }
         __syncthreads();
         if (tid == 0) wsum[kWaves] = 0;                                  // read again only after the next two barriers
         STAMP(4);
@@ -200,7 +243,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
             }
         }
-        if (a.cn_adj16) {
+        if constexpr (CNMODE != 0) {
             uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)blockIdx.x * a.D + p) * (size_t)(S >> 2);
             const uint2 *src = reinterpret_cast<const uint2 *>(stage);
             for (int w = tid; w < (S >> 2); w += kThreads) dst[w] = src[w];
@@ -231,27 +274,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     STAMP_FLUSH();
 }
 
-}  // namespace
-
-// 1 when scldpc_sample_philox_device_cn16 takes this ensemble, else 0 (callers then use scldpc_sample_philox_device_adj16)
-extern "C" int scldpc_sample_philox_cn16_supported(const scldpc_code_params *p)
+int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials,
+              double eps, int32_t ndoped, const int32_t *doped_positions, uint16_t *d_vn_adj16, uint16_t *d_table,
+              uint32_t *d_chan_bits, void *stream)
 {
-    if (scldpc::check_params(p)) return 0;
-    const int S = p->cns_pos * p->dc;
-    return p->dv == 4 && p->dc == 8 && (S & 3) == 0 && S <= 4096 && p->vns_pos * p->dv == S && scldpc::n_of(p) < 65535;
-}
-
-extern "C" int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
-                                                int32_t ntrials, double eps, int32_t ndoped,
-                                                const int32_t *doped_positions, uint16_t *d_vn_adj16,
-                                                uint16_t *d_cn_adj16, uint32_t *d_chan_bits, void *stream)
-{
-    const char *who = "scldpc_sample_philox_device_cn16";
-    if (int rc = scldpc::check_params(p)) return rc;
-    if (!scldpc_sample_philox_cn16_supported(p))
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 4096 sockets per position and "
-                                 "fewer than 65535 VNs (got dv=%d dc=%d cns_pos=%d n=%d)", who, p->dv, p->dc, p->cns_pos,
-                                 scldpc::n_of(p));
     if (ntrials < 0 || (ntrials > 0 && (!d_vn_adj16 || !d_chan_bits)))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
     if (ndoped < 0 || ndoped > kMaxDoped || (ndoped > 0 && !doped_positions))
@@ -259,6 +285,7 @@ extern "C" int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uin
     if (!(eps >= 0.0 && eps <= 1.0))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: eps=%g outside [0,1]", who, eps);
     if (ntrials == 0) return SCLDPC_OK;
+    if (!d_table) cnmode = 0;
 
     S2Args a{};
     a.L = p->L; a.cns_pos = p->cns_pos; a.vns_pos = p->vns_pos;
@@ -283,17 +310,75 @@ extern "C" int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uin
     int off = (a.nb + 3) & ~3;
     a.off_gpk = off;   off += (a.S + 3) & ~3;
     a.off_win = off;   off += (2 * a.S + 3) & ~3;           // dv * S uint16
-    a.off_stage = off; off += (a.S / 2 + 3) & ~3;
+    a.off_stage = off; off += cnmode ? (a.S / 2 + 3) & ~3 : 0;
     a.off_wsum = off;  off += 32 + 2 * kWorkCap;
     const size_t lds_bytes = 4u * (size_t)off;
-    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
+    if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %zu bytes of LDS per trial", who, lds_bytes);
+    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_table; a.chan = d_chan_bits;
 
-    const int rows = a.nb / kThreads;                       // 1, 2 or 4
-    void (*kern)(const S2Args) = rows == 1 ? sample_philox_v2_kernel<1> : rows == 2 ? sample_philox_v2_kernel<2>
-                                                                                    : sample_philox_v2_kernel<4>;
+    using Kern = void (*)(const S2Args);
+    static const Kern table[4][3] = {
+        {sample_philox_v2_kernel<1, 1, 0>, sample_philox_v2_kernel<1, 1, 1>, sample_philox_v2_kernel<1, 1, 2>},
+        {sample_philox_v2_kernel<1, 2, 0>, sample_philox_v2_kernel<1, 2, 1>, sample_philox_v2_kernel<1, 2, 2>},
+        {sample_philox_v2_kernel<1, 4, 0>, sample_philox_v2_kernel<1, 4, 1>, sample_philox_v2_kernel<1, 4, 2>},
+        {sample_philox_v2_kernel<2, 8, 0>, sample_philox_v2_kernel<2, 8, 1>, sample_philox_v2_kernel<2, 8, 2>},
+    };
+    const int rows = a.nb / kThreads;                       // 1, 2, 4 (one Philox call per thread) or 8 (two)
+    const Kern kern = table[rows == 1 ? 0 : rows == 2 ? 1 : rows == 4 ? 2 : 3][cnmode];
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+bool v2_shape(const scldpc_code_params *p)
+{
+    if (scldpc::check_params(p)) return false;
+    const int S = p->cns_pos * p->dc;
+    return p->dv == 4 && p->dc == 8 && (S & 3) == 0 && S <= 8192 && p->vns_pos * p->dv == S;
+}
+
+}  // namespace
+
+// 1 when scldpc_sample_philox_device_cn16 takes this ensemble, else 0 (callers then use scldpc_sample_philox_device_adj16)
+extern "C" int scldpc_sample_philox_cn16_supported(const scldpc_code_params *p)
+{
+    return v2_shape(p) && scldpc::n_of(p) < 65535;
+}
+
+// 1 when scldpc_sample_philox_device_sock16 takes this ensemble (any chain length: the table holds sockets, not VNs)
+extern "C" int scldpc_sample_philox_sock16_supported(const scldpc_code_params *p)
+{
+    return v2_shape(p);
+}
+
+extern "C" int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                                int32_t ntrials, double eps, int32_t ndoped,
+                                                const int32_t *doped_positions, uint16_t *d_vn_adj16,
+                                                uint16_t *d_cn_adj16, uint32_t *d_chan_bits, void *stream)
+{
+    const char *who = "scldpc_sample_philox_device_cn16";
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (!scldpc_sample_philox_cn16_supported(p))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 8192 sockets per position and "
+                                 "fewer than 65535 VNs (got dv=%d dc=%d cns_pos=%d n=%d)", who, p->dv, p->dc, p->cns_pos,
+                                 scldpc::n_of(p));
+    return launch_v2(who, 1, p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_cn_adj16, d_chan_bits,
+                     stream);
+}
+
+extern "C" int scldpc_sample_philox_device_sock16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0,
+                                                  int32_t ntrials, double eps, int32_t ndoped,
+                                                  const int32_t *doped_positions, uint16_t *d_vn_adj16,
+                                                  uint16_t *d_cn_sock16, uint32_t *d_chan_bits, void *stream)
+{
+    const char *who = "scldpc_sample_philox_device_sock16";
+    if (int rc = scldpc::check_params(p)) return rc;
+    if (!scldpc_sample_philox_sock16_supported(p))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8 and at most 8192 sockets per position "
+                                 "(got dv=%d dc=%d cns_pos=%d)", who, p->dv, p->dc, p->cns_pos);
+    return launch_v2(who, 2, p, seed, trial0, ntrials, eps, ndoped, doped_positions, d_vn_adj16, d_cn_sock16, d_chan_bits,
+                     stream);
 }

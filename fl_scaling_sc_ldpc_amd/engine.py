@@ -140,7 +140,7 @@ def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=
 
 
 def cn16_supported(p):
-    """The (4,8) chain with N <= 1024: the second-generation sampler + the 4-bits-per-CN decoder take it."""
+    """The (4,8) chain with N <= 2048 and fewer than 65535 VNs: the second-generation sampler + the 4-bits-per-CN decoder take it."""
     return bool(lib().scldpc_sample_philox_cn16_supported(C.byref(p))) and bool(lib().scldpc_full_bp_cn16_supported(C.byref(p)))
 
 
@@ -160,6 +160,33 @@ def sample_philox_cn16(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0",
                                                  dptr, d_adj.data_ptr(), d_cn.data_ptr() if d_cn is not None else None,
                                                  d_ch.data_ptr(), _stream_ptr(d_adj.device)))
     return d_adj, d_cn, d_ch
+
+
+def sw_ring_supported(p, W):
+    """Whether the window-state-in-LDS decoder (sw_ring.hip) takes the square window W on this ensemble."""
+    return bool(lib().scldpc_sw_bp_ring_supported(C.byref(p), int(W)))
+
+
+def sock16_supported(p):
+    """The (4,8) chain with N <= 2048: the second-generation sampler emits the ring window decoder's CN -> socket table."""
+    return bool(lib().scldpc_sample_philox_sock16_supported(C.byref(p)))
+
+
+def sample_philox_sock16(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=None):
+    """scldpc_sample_philox_device_sock16: (vn_adj16 int16 [T,n,4], cn_sock16 int16 [T,nk,8], chan int32 [T,nw]); the first
+    and the last are bit for bit sample_philox(..., adj16=True)'s, cn_sock16 is cn_sockets(p, vn_adj16) as a set per CN."""
+    _require_gpu()
+    if out is None:
+        d_adj = torch.empty((ntrials, p.n, p.dv), dtype=torch.int16, device=device)
+        d_cs = torch.empty((ntrials, p.nk, p.dc), dtype=torch.int16, device=device)
+        d_ch = torch.empty((ntrials, p.nw), dtype=torch.int32, device=device)
+    else:
+        d_adj, d_cs, d_ch = out
+    darr, dptr = _lib.doped_array(doped)
+    check(lib().scldpc_sample_philox_device_sock16(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size,
+                                                   dptr, d_adj.data_ptr(), d_cs.data_ptr(), d_ch.data_ptr(),
+                                                   _stream_ptr(d_adj.device)))
+    return d_adj, d_cs, d_ch
 
 
 def cn_adj_from_vn_adj(p, adj16):

@@ -170,16 +170,23 @@ int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t nt
                                          int32_t *d_counters, uint32_t *d_erased_bits, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* The same pair — generate_code + channel_doped (BPF:1656-1761, 1547-1574), then decodeBP to its fixpoint (BPF:900-1140) —
- * for the (dv = 4, dc = 8) chain with at most 4096 sockets per CN position (N <= 1024: the BASELINE ensemble), in the form
- * the throughput path of bench.py runs:
+ * for the (dv = 4, dc = 8) chain with at most 8192 sockets per CN position (N <= 2048; the BASELINE ensemble has 4000), in
+ * the form the throughput path of bench.py runs:
  *   scldpc_sample_philox_device_cn16      same keys, same law, same d_vn_adj16 / d_chan_bits as scldpc_sample_philox_device_adj16,
  *                                         plus (d_cn_adj16 may be NULL) the CN -> VN table uint16 [ntrials][nk][dc]: the VNs
  *                                         attached to every CN (global VN index; needs n < 65535), 0xFFFF where a CN at a
  *                                         chain end has fewer than dc (BPF:1703-1716).  Order within a CN unspecified (a set).
  *   scldpc_full_bp_fixpoint_device_cn16   counters of scldpc_full_bp_fixpoint_device from both tables: 4 bits of LDS per CN,
  *                                         seven trials per CU in flight (full_bp_small.hip).
+ *   scldpc_sample_philox_device_sock16    the same sampler emitting, instead of the CN -> VN table, the CN -> socket table
+ *                                         d_cn_sock16 of scldpc_sw_bp_ring_device below (what scldpc_cn_sockets_device
+ *                                         builds in a second pass); sockets are position-local, so any chain length.
  * *_supported: 1 if the ensemble is taken, else 0 (use the _adj16 entry points). */
 int scldpc_sample_philox_cn16_supported(const scldpc_code_params *p);
+int scldpc_sample_philox_sock16_supported(const scldpc_code_params *p);
+int scldpc_sample_philox_device_sock16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials,
+                                       double eps, int32_t ndoped, const int32_t *doped_positions, uint16_t *d_vn_adj16,
+                                       uint16_t *d_cn_sock16, uint32_t *d_chan_bits, void *stream);
 int scldpc_sample_philox_device_cn16(const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials,
                                      double eps, int32_t ndoped, const int32_t *doped_positions, uint16_t *d_vn_adj16,
                                      uint16_t *d_cn_adj16, uint32_t *d_chan_bits, void *stream);

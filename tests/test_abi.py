@@ -153,12 +153,19 @@ def test_second_generation_entry_points_refuse_what_they_do_not_take(L):
     P = _lib.CodeParams
     base, wide, long_, big, odd = P(4, 8, 50, 500, 1000), P(4, 8, 50, 512, 1024), P(4, 8, 100, 500, 1000), P(4, 8, 100, 1000, 2000), P(3, 6, 20, 100, 200)
     assert L.scldpc_sample_philox_cn16_supported(C.byref(base)) == 1 and L.scldpc_full_bp_cn16_supported(C.byref(base)) == 1
-    assert L.scldpc_sample_philox_cn16_supported(C.byref(wide)) == 1                 # 4096 sockets per position: the limit
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(wide)) == 1 and L.scldpc_sample_philox_cn16_supported(C.byref(P(4, 8, 20, 1024, 2048))) == 1
+    too_wide = P(4, 8, 20, 1025, 2050)                                                 # 8192 sockets per position: the limit
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(too_wide)) == 0 and L.scldpc_sample_philox_sock16_supported(C.byref(too_wide)) == 0
+    assert L.scldpc_sample_philox_sock16_supported(C.byref(big)) == 1                 # sockets are position-local: any chain length
+    assert L.scldpc_sample_philox_sock16_supported(C.byref(odd)) == 0
+    assert L.scldpc_sample_philox_device_sock16(C.byref(too_wide), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -2
+    assert L.scldpc_sample_philox_device_sock16(C.byref(big), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -1    # null buffers
+    assert L.scldpc_sample_philox_device_sock16(C.byref(big), 1, 0, 0, 0.5, 0, None, None, None, None, None) == 0     # empty batch
     assert L.scldpc_full_bp_cn16_supported(C.byref(long_)) == 0                       # n = 100 000 VNs: ids beyond 16 bits
-    assert L.scldpc_sample_philox_cn16_supported(C.byref(big)) == 0                   # 8000 sockets per position
+    assert L.scldpc_sample_philox_cn16_supported(C.byref(big)) == 0                   # n = 200 000 VNs: ids beyond 16 bits
     assert L.scldpc_sample_philox_cn16_supported(C.byref(odd)) == 0 and L.scldpc_full_bp_cn16_supported(C.byref(odd)) == 0
     assert L.scldpc_sample_philox_device_cn16(C.byref(big), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -2
-    assert b"4096" in L.scldpc_last_error()
+    assert b"65535" in L.scldpc_last_error()
     assert L.scldpc_full_bp_fixpoint_device_cn16(C.byref(long_), 4, None, None, None, 1, None, None, None) == -2
     assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 0, 0.5, 0, None, None, None, None, None) == 0      # empty batch
     assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -1     # null buffers

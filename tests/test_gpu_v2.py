@@ -28,7 +28,9 @@ def _check_cn_table(E, p, adj16, cn16):
 
 @pytest.mark.parametrize("L,N,eps,doped", [(50, 1000, 0.48, ()), (10, 10, 0.48, ()), (20, 100, 0.3, (3, 4)), (7, 66, 0.9, ()),
                                            (50, 1000, 0.48, (24, 25)), (12, 1024, 0.45, (5,)), (5, 128, 0.0, ()),
-                                           (5, 128, 1.0, (0,)), (16, 512, 0.5, ()), (9, 600, 0.47, ())])
+                                           (5, 128, 1.0, (0,)), (16, 512, 0.5, ()), (9, 600, 0.47, ()),
+                                           # more than 4096 sockets per position: two Philox calls per thread
+                                           (7, 2048, 0.47, (2,)), (12, 1100, 0.5, ()), (15, 2000, 0.48, ()), (6, 1028, 0.4, ())])
 def test_sampler_v2_equals_first_generation_and_twin(E, oracle, L, N, eps, doped):
     import torch
     p = E.make_params(4, 8, L, N)
@@ -132,6 +134,31 @@ def test_cn_socket_table_is_the_inverse_of_the_vn_table(E):
                 back = A[t].reshape(L, N, 4)[np.clip(q, 0, L - 1), np.clip(tt, 0, N - 1), i]
                 assert (back == np.arange(p.cns_pos)[:, None])[valid].all()
                 assert valid.sum() == sum(N for k in range(4) if 0 <= cpos - k < L)
+
+
+@pytest.mark.parametrize("L,N,W,eps,doped", [(100, 2000, 10, 0.47, ()), (50, 1000, 10, 0.47, (20,)), (10, 10, 4, 0.48, ()),
+                                             (9, 24, 2, 0.5, (0, 8)), (14, 1200, 5, 0.47, ()), (30, 2048, 6, 0.46, ())])
+def test_sampler_emits_the_socket_table_of_the_ring_decoder(E, L, N, W, eps, doped):
+    """scldpc_sample_philox_device_sock16: the code and channel of the first-generation sampler bit for bit, and — as a set
+    per CN — the table scldpc_cn_sockets_device builds from that code in a second pass; the ring decoder gives the same
+    counters and residual pattern from either table.  N = 2000, L = 100 is BASELINE config 4 (200 000 VNs: the table holds
+    position-local sockets, not VN indices)."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    assert E.sock16_supported(p) and E.sw_ring_supported(p, W)
+    T = 24 if N >= 1000 else 96
+    a1, c1 = E.sample_philox(p, 31, 7000, T, eps, doped, adj16=True)
+    a2, cs2, c2 = E.sample_philox_sock16(p, 31, 7000, T, eps, doped)
+    cs1 = E.cn_sockets(p, a1)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(c1, c2)
+    s1 = np.sort(cs1.cpu().numpy().view(np.uint16), axis=2)
+    s2 = np.sort(cs2.cpu().numpy().view(np.uint16), axis=2)
+    assert (s1 == s2).all()
+    r1 = E.sw_bp(p, a1, c1, W, 20, 0, want_erased=True, ring=True, d_cn_sock=cs1)
+    r2 = E.sw_bp(p, a2, c2, W, 20, 0, want_erased=True, ring=True, d_cn_sock=cs2)
+    torch.cuda.synchronize()
+    assert torch.equal(r1["counters"], r2["counters"]) and torch.equal(r1["erased"], r2["erased"])
 
 
 @pytest.mark.parametrize("name", golden_names(variants=("bpw",)))
