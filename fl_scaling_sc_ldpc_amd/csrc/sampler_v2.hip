@@ -35,7 +35,7 @@ struct S2Args {
     uint32_t seed_lo, seed_hi;
     unsigned long long trial0;
     uint32_t thresh;                    // erased iff (draw >> 1) < thresh
-    int off_gpk, off_win, off_stage, off_wsum;      // LDS offsets in 32-bit words
+    int off_gpk, off_fix, off_stage, off_wsum;      // LDS offsets in 32-bit words
     uint16_t *vn_adj16;                 // uint16 [T][n][4], CN index local to its position
     uint16_t *cn_adj16;                 // uint16 [T][D*cns_pos][8] VNs of every CN (0xFFFF: none), or null
     uint32_t *chan;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                               // nb words of four nibble-wide bucket counters
     uint32_t *gpk = lds + a.off_gpk;                                    // S words: packed keys of straddling buckets
-    uint16_t *win = reinterpret_cast<uint16_t *>(lds + a.off_win);      // ring of dv x S CN-local ids
+    uint16_t *fix = reinterpret_cast<uint16_t *>(lds + a.off_fix);      // S CN-local ids: the true CN of a straddling key
     uint16_t *stage = reinterpret_cast<uint16_t *>(lds + a.off_stage);  // the S sockets (or their VNs) in rank order
     uint32_t *wsum = lds + a.off_wsum;                                  // 16 wave totals + the worklist counter
     uint32_t *wl = wsum + 32;                                           // worklist: 2 words per key of a straddling bucket
@@ -106,6 +106,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     __syncthreads();
     // The keys of position p+1 are drawn (pure VALU) while the few worklist lanes of position p chase their bucket mates
     // through the LDS: nxt[] carries them across the barrier.
+    // Thread t draws the keys of sockets 4t .. 4t+3 of every CN position, and socket 4t+i of CN position q+i is edge i of
+    // VN (q, t) (BPF:1712): the row of a VN is assembled in its thread's registers over dv consecutive positions.
+    // Entering step p: rowP = [edge 0 @ p-3 | edge 1 @ p-2], rowQ = [edge 0 @ p-2 | edge 1 @ p-1], rowR = [edge 0 @ p-1 | edge 2 @ p-1]
+    uint32_t rowP[KMAX], rowQ[KMAX], rowR[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) rowP[k] = rowQ[k] = rowR[k] = 0;
     uint32_t nxt[E];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         // ---- classify: every key gets rank g0 + arrival slot — any bijection onto its bucket's ranks gives the right CN
         //      (g0 / dc) when the bucket lies inside one block of dc ranks.  CN ids go into the ring, sockets into the
         //      rank-ordered stage.  Keys of buckets that span two CNs (3 %) are also put on a worklist for their true rank.
-        uint16_t *wp = win + (size_t)(p & 3) * S;
+        uint32_t cn[E], fixmask;                                          // CN-local id of every key; keys whose id the worklist decides
         {
             uint32_t h[E], rk[E], g0a[E], cnta[E], smask = 0;
 #pragma unroll
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 rk[e] = g0a[e] + slot[e];
                 if (own[e >> 2] && ((g0a[e] + cnta[e] - 1u) >> DC_SHIFT) != (g0a[e] >> DC_SHIFT)) smask |= 1u << e;
             }
+            fixmask = smask;
             while (smask) {                                             // rare (3 % of the keys): one short divergent loop
                 const uint32_t e = (uint32_t)__ffs((int)smask) - 1u;
                 smask &= smask - 1u;
@@ -182,16 +189,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 if (w < kWorkCap) { wl[2 * w] = g0 | (cnt << 16) | (sl << 20); wl[2 * w + 1] = pk; }
             }
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
-                if (!own[k]) continue;
-                if constexpr (CNMODE != 0) {
+            for (int e = 0; e < E; e++) cn[e] = rk[e] >> DC_SHIFT;
+            if constexpr (CNMODE != 0) {
+#pragma unroll
+                for (int k = 0; k < KMAX; k++) {
+                    if (!own[k]) continue;
 #pragma unroll
                     for (int u = 0; u < 4; u++) stage[rk[4 * k + u]] = stage_entry(p, sock(4 * k + u));
                 }
-                uint2 v;
-                v.x = (rk[4 * k] >> DC_SHIFT) | ((rk[4 * k + 1] >> DC_SHIFT) << 16);
-                v.y = (rk[4 * k + 2] >> DC_SHIFT) | ((rk[4 * k + 3] >> DC_SHIFT) << 16);
-                *reinterpret_cast<uint2 *>(wp + (tid + k * kThreads) * 4) = v;
             }
         }
         __syncthreads();
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                     if (m != sl) r += gpk[g0 + m] < pk;
                 const uint32_t sck = pk & ((1u << a.sbits) - 1u);
                 if constexpr (CNMODE != 0) stage[r] = stage_entry(p, sck);
-                wp[sck] = (uint16_t)(r >> DC_SHIFT);
+                fix[sck] = (uint16_t)(r >> DC_SHIFT);
             }
         }
         if (p + 1 < a.D) {
@@ -229,19 +234,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         if (tid == 0) wsum[kWaves] = 0;                                  // read again only after the next two barriers
         STAMP(4);
 
-        // ---- VN position q = p-dv+1 now has all its dv permutations in the ring (BPF:1703-1716); CN position p its sockets
+        // ---- VN position q = p-dv+1 now has all its dv edges (BPF:1703-1716); CN position p its sockets
+        while (fixmask) {                                               // the few keys whose CN the worklist decided
+            const uint32_t e = (uint32_t)__ffs((int)fixmask) - 1u;
+            fixmask &= fixmask - 1u;
+            const uint32_t c = fix[(tid + (int)(e >> 2) * kThreads) * 4 + (int)(e & 3u)];
+#pragma unroll
+            for (int f = 0; f < E; f++)
+                if (e == (uint32_t)f) cn[f] = c;
+        }
         const int qpos = p - (DV - 1);
-        if (qpos >= 0) {
-            for (int t = tid; t < a.vns_pos; t += kThreads) {
-                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
-                const uint32_t l0 = win[(size_t)((qpos + 0) & 3) * S + 4 * t + 0];
-                const uint32_t l1 = win[(size_t)((qpos + 1) & 3) * S + 4 * t + 1];
-                const uint32_t l2 = win[(size_t)((qpos + 2) & 3) * S + 4 * t + 2];
-                const uint32_t l3 = win[(size_t)((qpos + 3) & 3) * S + 4 * t + 3];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            // this step drew edge 0 of VN position p, edge 1 of p-1, edge 2 of p-2 and edge 3 of p-3 = qpos
+            if (qpos >= 0 && own[k]) {
+                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + (size_t)(tid + k * kThreads);
                 uint2 v;
-                v.x = l0 | (l1 << 16); v.y = l2 | (l3 << 16);
+                v.x = rowP[k];
+                v.y = (rowR[k] >> 16) | (cn[4 * k + 3] << 16);
                 reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
             }
+            rowP[k] = rowQ[k];
+            rowQ[k] = (rowR[k] & 0xFFFFu) | (cn[4 * k + 1] << 16);
+            rowR[k] = cn[4 * k] | (cn[4 * k + 2] << 16);
         }
         if constexpr (CNMODE != 0) {
             uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)blockIdx.x * a.D + p) * (size_t)(S >> 2);
@@ -309,7 +324,7 @@ int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t
     }
     int off = (a.nb + 3) & ~3;
     a.off_gpk = off;   off += (a.S + 3) & ~3;
-    a.off_win = off;   off += (2 * a.S + 3) & ~3;           // dv * S uint16
+    a.off_fix = off;   off += (a.S / 2 + 3) & ~3;           // S uint16
     a.off_stage = off; off += cnmode ? (a.S / 2 + 3) & ~3 : 0;
     a.off_wsum = off;  off += 32 + 2 * kWorkCap;
     const size_t lds_bytes = 4u * (size_t)off;
