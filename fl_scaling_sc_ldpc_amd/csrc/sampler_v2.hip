@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                               // nb words of four nibble-wide bucket counters
     uint32_t *gpk = lds + a.off_gpk;                                    // S words: packed keys of straddling buckets
-    uint16_t *fix = reinterpret_cast<uint16_t *>(lds + a.off_fix);      // S CN-local ids: the true CN of a straddling key
+    uint16_t *fix = reinterpret_cast<uint16_t *>(lds + a.off_fix);      // S CN-local ids of this position's sockets
     uint16_t *stage = reinterpret_cast<uint16_t *>(lds + a.off_stage);  // the S sockets (or their VNs) in rank order
     uint32_t *wsum = lds + a.off_wsum;                                  // 16 wave totals + the worklist counter
     uint32_t *wl = wsum + 32;                                           // worklist: 2 words per key of a straddling bucket
@@ -126,13 +126,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         uint32_t key[E], slot[E], crowded = 0;
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            key[e] = nxt[e];
-            slot[e] = 0;
-            if (own[e >> 2]) {
-                const uint32_t b = key[e] >> kshift, sh = (b & 3u) * 4u;
-                slot[e] = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 0xFu;
-                crowded = max(crowded, slot[e]);
-            }
+            key[e] = nxt[e];                                            // (threads without sockets hold zero keys and add zero)
+            const uint32_t b = key[e] >> kshift, sh = (b & 3u) * 4u;
+            slot[e] = (atomicAdd(&hist[b >> 2], (own[e >> 2] ? 1u : 0u) << sh) >> sh) & 0xFu;
+            crowded = max(crowded, slot[e]);
         }
         if (crowded >= 15u) __builtin_trap();                           // a bucket count must fit its nibble (never happens:
         __syncthreads();                                                // 0.24 keys per bucket on average)
@@ -144,7 +141,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
             uint32_t x[ROWS], v[ROWS], tot = 0;
             load_words(x);
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) { v[r] = nib_sum(x[r]); tot += v[r]; }
+            for (int r = 0; r < ROWS; r++) v[r] = 0;
+            if constexpr (ROWS % 2 == 0) {                              // two words' counters (16 bits each) per 32-bit lane
+#pragma unroll
+                for (int r = 0; r < ROWS; r += 2) {
+                    const uint32_t y = x[r] | (x[r + 1] << 16);
+                    const uint32_t sb = (y & 0x0F0F0F0Fu) + ((y >> 4) & 0x0F0F0F0Fu);      // four byte sums <= 30
+                    v[r] = (sb & 0xFFu) + ((sb >> 8) & 0xFFu);
+                    v[r + 1] = ((sb >> 16) & 0xFFu) + (sb >> 24);
+                    tot += v[r] + v[r + 1];
+                }
+            } else {
+                static_assert(ROWS == 1 || ROWS % 2 == 0, "ROWS is 1, 2, 4 or 8");
+                v[0] = nib_sum(x[0]);
+                tot = v[0];
+            }
             const uint32_t inc = wave_inclusive_scan(tot);
             if (lane == 63) wsum[wave] = inc;
             __syncthreads();
@@ -161,7 +172,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         // ---- classify: every key gets rank g0 + arrival slot — any bijection onto its bucket's ranks gives the right CN
         //      (g0 / dc) when the bucket lies inside one block of dc ranks.  CN ids go into the ring, sockets into the
         //      rank-ordered stage.  Keys of buckets that span two CNs (3 %) are also put on a worklist for their true rank.
-        uint32_t cn[E], fixmask;                                          // CN-local id of every key; keys whose id the worklist decides
         {
             uint32_t h[E], rk[E], g0a[E], cnta[E], smask = 0;
 #pragma unroll
@@ -175,7 +185,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 rk[e] = g0a[e] + slot[e];
                 if (own[e >> 2] && ((g0a[e] + cnta[e] - 1u) >> DC_SHIFT) != (g0a[e] >> DC_SHIFT)) smask |= 1u << e;
             }
-            fixmask = smask;
             while (smask) {                                             // rare (3 % of the keys): one short divergent loop
                 const uint32_t e = (uint32_t)__ffs((int)smask) - 1u;
                 smask &= smask - 1u;
@@ -189,7 +198,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
                 if (w < kWorkCap) { wl[2 * w] = g0 | (cnt << 16) | (sl << 20); wl[2 * w + 1] = pk; }
             }
 #pragma unroll
-            for (int e = 0; e < E; e++) cn[e] = rk[e] >> DC_SHIFT;
+            for (int k = 0; k < KMAX; k++) {                            // provisional CN ids (final unless on the worklist)
+                if (!own[k]) continue;
+                uint2 v;
+                v.x = (rk[4 * k] >> DC_SHIFT) | ((rk[4 * k + 1] >> DC_SHIFT) << 16);
+                v.y = (rk[4 * k + 2] >> DC_SHIFT) | ((rk[4 * k + 3] >> DC_SHIFT) << 16);
+                reinterpret_cast<uint2 *>(fix)[tid + k * kThreads] = v;
+            }
             if constexpr (CNMODE != 0) {
 #pragma unroll
                 for (int k = 0; k < KMAX; k++) {
@@ -222,10 +237,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
             }
         }
         if (p + 1 < a.D) {
+            // the round keys are recomputed from the seed here (twenty scalar adds) rather than kept in twenty SGPRs across
+            // the whole loop, which the 72-SGPR budget of two workgroups per CU would spill into VGPR lanes
+            uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
+            asm volatile("" : "+s"(k_lo), "+s"(k_hi));
 #pragma unroll
             for (int k = 0; k < KMAX; k++) {
                 uint32_t r[4] = {0, 0, 0, 0};
-                if (own[k]) philox4x32_10((uint32_t)(tid + k * kThreads), (uint32_t)(p + 1), t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+                if (own[k]) philox4x32_10((uint32_t)(tid + k * kThreads), (uint32_t)(p + 1), t_lo, t_hi, k_lo, k_hi, r);
 #pragma unroll
                 for (int u = 0; u < 4; u++) nxt[4 * k + u] = r[u];
             }
@@ -235,28 +254,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         STAMP(4);
 
         // ---- VN position q = p-dv+1 now has all its dv edges (BPF:1703-1716); CN position p its sockets
-        while (fixmask) {                                               // the few keys whose CN the worklist decided
-            const uint32_t e = (uint32_t)__ffs((int)fixmask) - 1u;
-            fixmask &= fixmask - 1u;
-            const uint32_t c = fix[(tid + (int)(e >> 2) * kThreads) * 4 + (int)(e & 3u)];
-#pragma unroll
-            for (int f = 0; f < E; f++)
-                if (e == (uint32_t)f) cn[f] = c;
-        }
         const int qpos = p - (DV - 1);
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
             // this step drew edge 0 of VN position p, edge 1 of p-1, edge 2 of p-2 and edge 3 of p-3 = qpos
+            uint2 c = make_uint2(0u, 0u);                               // [edge 0 | edge 1], [edge 2 | edge 3] of this step
+            if (own[k]) c = reinterpret_cast<const uint2 *>(fix)[tid + k * kThreads];
             if (qpos >= 0 && own[k]) {
                 const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + (size_t)(tid + k * kThreads);
                 uint2 v;
                 v.x = rowP[k];
-                v.y = (rowR[k] >> 16) | (cn[4 * k + 3] << 16);
+                v.y = (rowR[k] >> 16) | (c.y & 0xFFFF0000u);
                 reinterpret_cast<uint2 *>(a.vn_adj16)[j] = v;
             }
             rowP[k] = rowQ[k];
-            rowQ[k] = (rowR[k] & 0xFFFFu) | (cn[4 * k + 1] << 16);
-            rowR[k] = cn[4 * k] | (cn[4 * k + 2] << 16);
+            rowQ[k] = (rowR[k] & 0xFFFFu) | (c.x & 0xFFFF0000u);
+            rowR[k] = (c.x & 0xFFFFu) | (c.y << 16);
         }
         if constexpr (CNMODE != 0) {
             uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)blockIdx.x * a.D + p) * (size_t)(S >> 2);

@@ -1,21 +1,35 @@
 #!/bin/bash
-# SQ / LDS counters for the bench workload (own pass, no tracing flags beyond what rocprofv3 needs for PMC).
-set -e
-TAG=${1:-r01}
+# Run on the GPU box from the repo root: SQ counters (VALU / LDS / wait cycles) of the two throughput kernels,
+# one rocprofv3 --pmc pass per group, on tools/ab_v2.py.  Output: gpurun_out/pmc_sq/*.csv + a per-kernel summary.
+TAG=${1:-sq}
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/pmc_sq_$TAG
-rm -rf $OUT; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_ATOMIC_RETURN --output-format csv -d $OUT/b -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/b.log 2>&1
+rocprofv3 --list-avail > $OUT/avail.txt 2>&1
+i=0
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
+           "SQ_INST_CYCLES_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_WAVE32_LDS" ; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $ROOT/tools/ab_v2.py 4096 1 > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
+  echo "group $i done"
+done
 python3 - <<PY
 import csv, glob, collections
-for sub in ('a','b'):
-    for f in glob.glob('$OUT/'+sub+'/*/*_counter_collection.csv'):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            k = 'full_bp' if 'full_bp_kernel' in r['Kernel_Name'] else 'sample' if 'sample_philox' in r['Kernel_Name'] else None
-            if k: agg[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
-        for (k, c), v in sorted(agg.items()):
-            print(f"{k:8s} {c:24s} {sum(v)/len(v):16.0f}")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt", "w") as o:
+    for k, d in agg.items():
+        if "philox_v2" not in k and "full_bp_small" not in k: continue
+        o.write(k + "\n")
+        for c, v in sorted(d.items()):
+            o.write(f"   {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})\n")
+print(open("$OUT/summary.txt").read())
 PY
