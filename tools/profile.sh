@@ -19,4 +19,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROO
 echo "write done"
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_rdreq -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_rdreq.log 2>&1 || echo "rdreq pass failed"
 echo "rdreq done"
+# instruction mix / pipe occupancy of the two kernels (SQ counters are in units of 4 cycles per SIMD where they count time)
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
+           "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_sq$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_sq$i.log 2>&1 || echo "sq pass $i failed"
+done
+echo "sq done"
 find $OUT -name "*.csv" | head -20

@@ -86,6 +86,43 @@ def main():
                          f"calibrated by tools/calib -> profiles/{tag}_calibration.txt)"},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+    # ---- SQ counters: instruction mix and pipe occupancy (which pipe bounds which kernel)
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    span = collections.defaultdict(list)
+    for d in sorted(glob.glob(os.path.join(src, "pmc_sq*"))):
+        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            k = short(r["Kernel_Name"])
+            if k:
+                sq[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                span[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    if sq:
+        SIMDS, CUS, GHZ = 1024, 256, 2.4
+        with open(os.path.join(dst, f"{tag}_sq_counters.txt"), "w") as f:
+            f.write(f"rocprofv3 --pmc <SQ group> -- python3 bench.py --steps 2 --warmup 1 (three passes), {batch} trials per launch;\n"
+                    "means per dispatch.  SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count in units of 4 cycles (one issue slot of a\n"
+                    f"SIMD); pipe shares assume {SIMDS} SIMDs, {CUS} CUs and {GHZ} GHz over the dispatch's own duration.\n\n")
+            for k, c in sq.items():
+                m = {n: mean(v) for n, v in c.items()}
+                ns = mean(span[k])
+                quads = ns * GHZ / 4 * SIMDS
+                f.write(f"{k}   ({ns / 1e6:.3f} ms per dispatch under the profiler)\n")
+                for n in sorted(m):
+                    f.write(f"    {n:24s} {m[n]:16.0f}\n")
+                w = m.get("SQ_WAVES")
+                if w:
+                    f.write("    per wave: " + "  ".join(f"{n[9:]}={m[n] / w:.0f}" for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if n in m) + "\n")
+                if "SQ_ACTIVE_INST_VALU" in m:
+                    f.write(f"    VALU issue slots busy: {m['SQ_ACTIVE_INST_VALU'] / quads:.2f} of the SIMDs' time\n")
+                if "SQ_LDS_IDX_ACTIVE" in m:
+                    f.write(f"    LDS pipe busy: {m['SQ_LDS_IDX_ACTIVE'] / (ns * GHZ * CUS):.2f} of the CUs' time "
+                            f"({m.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, m['SQ_LDS_IDX_ACTIVE']):.2f} of it bank conflicts)\n")
+                if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" not in m:
+                    pass
+                f.write("\n")
+        print(open(os.path.join(dst, f"{tag}_sq_counters.txt")).read())
 
 
 if __name__ == "__main__":
