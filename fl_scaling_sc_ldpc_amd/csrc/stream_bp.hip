@@ -28,12 +28,12 @@ namespace {
 using namespace scldpc_dev;
 
 constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kMaxL = 256;
-constexpr int kQCapTwo = 2048, kQCapOne = 8192;     // frontier-queue entries with two / one workgroup(s) per CU
+constexpr int kQCap = 2048;                         // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
-    size_t adj, inter, sbits, ebits, cn, poscnt, tk, gkey, tslot, gidx, counters, total;
+    size_t adj, inter, sbits, ebits, cn, poscnt, gkey, gidx, counters, total;
     int wpp;                // 32-bit words of S / VNerased per position
 };
 
@@ -69,15 +69,17 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
 // ROWS <= 4 (at most 4096 counter words, N <= 1024 at (4,8)): the LDS part is 34 KB, so two workgroups fit a CU if the
 // compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip) — the kernel waits on L2 round trips most of the time and a second
 // stream on the CU hides them.  Larger ensembles need the whole LDS for the counters and keep the registers they want.
-template <int ROWS, int kQCap>
+template <int ROWS>
 __device__ __forceinline__ void stream_bp_body(const Args &a)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *hist = lds;                                   // nb bucket counters (ranking)
-    uint32_t *q0 = lds + a.nb, *q1 = q0 + kQCap;            // frontier queues
-    uint32_t *wsum = q1 + kQCap, *wpre = wsum + 32;         // scan scratch
-    int *pos_cnt = reinterpret_cast<int *>(wpre + kWaves * kWaves);   // [L] erased VNs per ring slot
+    uint32_t *hist = lds;                                   // nb 16-bit bucket counters, two per word (ranking)
+    uint32_t *q0 = lds + a.nb / 2, *q1 = q0 + kQCap;        // frontier queues
+    uint32_t *wsum = q1 + kQCap;                            // scan scratch
+    int *pos_cnt = reinterpret_cast<int *>(wsum + 32);      // [L] erased VNs per ring slot
     int *scal = pos_cnt + kMaxL;
+    long long *acc = reinterpret_cast<long long *>(scal + S_NSCAL);      // the eight running totals: thread 0's alone
+    uint8_t *tsl = reinterpret_cast<uint8_t *>(acc + 8);                 // [S] arrival slot of every socket's key in its bucket
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, ms = a.dv - 1, W = a.W, wpp = a.lay.wpp;
@@ -88,18 +90,18 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
     uint32_t *Eb = reinterpret_cast<uint32_t *>(st + a.lay.ebits);         // [L][wpp] VNerased
     uint32_t *cn = reinterpret_cast<uint32_t *>(st + a.lay.cn);            // [L*C]
     int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
-    uint32_t *tk = reinterpret_cast<uint32_t *>(st + a.lay.tk), *gkey = reinterpret_cast<uint32_t *>(st + a.lay.gkey);
-    uint16_t *tslot = reinterpret_cast<uint16_t *>(st + a.lay.tslot), *gidx = reinterpret_cast<uint16_t *>(st + a.lay.gidx);
+    uint32_t *gkey = reinterpret_cast<uint32_t *>(st + a.lay.gkey);       // [S] keys of straddling buckets, by rank slot
+    uint16_t *gidx = reinterpret_cast<uint16_t *>(st + a.lay.gidx);       // [S] and their sockets
     long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
     const unsigned long long sid = a.sid0 + blockIdx.x;
     const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
     auto ldcn = [&](int c) { return __hip_atomic_load(&cn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
+    STAMP_DECL
     for (int i = tid; i < L; i += kThreads) pos_cnt[i] = pos_cnt_g[i];
     if (tid < S_NSCAL) scal[tid] = 0;
     __syncthreads();
-    long long ne = cnt64[C_NE], be = cnt64[C_BE], ee = cnt64[C_EE], bee = cnt64[C_BEE];
-    long long gb = cnt64[C_GB], gbl = cnt64[C_GBL], gbe = cnt64[C_GBE], gble = cnt64[C_GBLE];
+    if (tid == 0) for (int k = C_NE; k <= C_GBLE; k++) acc[k] = cnt64[k];
     long long pos = cnt64[C_POS], gen = cnt64[C_GEN];
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
@@ -111,29 +113,45 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             __syncthreads();
             return;
         }
-        for (int b = tid; b < a.nb; b += kThreads) hist[b] = 0;
+        // Keys are never stored: Philox is pure VALU, so the three passes (count, classify, rank the straddlers) draw them
+        // again; what a pass hands to the next lives in LDS (16-bit prefix per bucket, one byte of arrival slot per socket)
+        // except the straddling buckets' keys, which are grouped in the stream's blob (3-15 % of the sockets).
+        const int ncalls = (S + 3) / 4;
+        for (int b = tid; b < a.nb / 2; b += kThreads) hist[b] = 0;
         __syncthreads();
-        for (int q = tid; q < (S + 3) / 4; q += kThreads) {
+        uint32_t crowded = 0;
+        for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
             philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int s = q * 4 + u;
-                if (s < S) { tk[s] = r[u]; tslot[s] = (uint16_t)atomicAdd(&hist[r[u] >> a.shift], 1u); }
+                if (s < S) {
+                    const uint32_t b = r[u] >> a.shift, sh = (b & 1u) * 16u;
+                    const uint32_t sl = (atomicAdd(&hist[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                    tsl[s] = (uint8_t)sl;
+                    crowded |= sl;
+                }
             }
         }
+        if (crowded >= 256u) __builtin_trap();              // arrival slots are kept in a byte (a bucket holds 1-4 keys on average)
         __syncthreads();
+        // wave w scans buckets [w, w+1) * nb/16 = ROWS * 32 words of two counters: exclusive prefix inside the chunk, then
+        // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits (S <= 65535)
+        constexpr int R2 = ROWS >= 2 ? ROWS / 2 : 1;
+        const bool on = ROWS >= 2 || lane < 32;
+        const int w0 = wave * (ROWS * 32) + lane;
         {
-            const int b0 = wave * (ROWS * 64) + lane;
-            uint32_t v[ROWS], inc[ROWS];
+            uint32_t v[R2], ps[R2], inc[R2];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) v[r] = hist[b0 + r * 64];
+            for (int r = 0; r < R2; r++) { v[r] = on ? hist[w0 + r * 64] : 0u; ps[r] = (v[r] & 0xFFFFu) + (v[r] >> 16); }
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
+            for (int r = 0; r < R2; r++) inc[r] = wave_inclusive_scan(ps[r]);
             uint32_t carry = 0;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                hist[b0 + r * 64] = carry + inc[r] - v[r];
+            for (int r = 0; r < R2; r++) {
+                const uint32_t ex = carry + inc[r] - ps[r];
+                if (on) hist[w0 + r * 64] = ex | ((ex + (v[r] & 0xFFFFu)) << 16);
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
             }
             if (lane == 0) wsum[wave] = carry;
@@ -142,10 +160,14 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         {
             const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
             const uint32_t inc = wave_inclusive_scan(t);
-            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(inc - t), wave);
+#pragma unroll
+            for (int r = 0; r < R2; r++)
+                if (on) hist[w0 + r * 64] += base * 0x10001u;   // both halves stay below 65536: no carry between them
         }
+        __syncthreads();
         auto bucket_base = [&](uint32_t b) -> uint32_t {
-            return b >= (uint32_t)a.nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
+            return b >= (uint32_t)a.nb ? (uint32_t)S : (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
         };
         // CN = rank / dc, so a bucket whose ranks [g0, g1) lie inside one block of dc ranks gives all its keys the same CN
         // whatever their order: only the keys of buckets that straddle a multiple of dc are grouped and compared.
@@ -153,30 +175,57 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             return g1 - g0 > 1u && (a.dc_shift >= 0 ? (g0 >> a.dc_shift) != ((g1 - 1u) >> a.dc_shift)
                                                     : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
         };
-        for (int s = tid; s < S; s += kThreads) {
-            const uint32_t k = tk[s], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
-            if (straddles(g0, g1)) { gkey[g0 + tslot[s]] = k; gidx[g0 + tslot[s]] = (uint16_t)s; }
+        auto cn_of = [&](uint32_t rank) { return (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc); };
+        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+        bool any = false;
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+            uint32_t c4[4] = {0, 0, 0, 0};                  // (a straddler's entry is written by the third pass)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s >= S) continue;
+                const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
+                if (!straddles(g0, g1)) { c4[u] = cn_of(g0); continue; }
+                const uint32_t at = g0 + tsl[s];
+                gkey[at] = k; gidx[at] = (uint16_t)s;
+                any = true;
+            }
+            if (q * 4 + 3 < S && (S & 3) == 0) {
+                *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
+            } else {
+                for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
+            }
         }
         __syncthreads();
-        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
-        for (int s = tid; s < S; s += kThreads) {
-            const uint32_t k = tk[s], b = k >> a.shift;
-            const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1), self = g0 + tslot[s];
-            uint32_t rank = g0;
-            if (straddles(g0, g1))
-                for (uint32_t g = g0; g < g1; g++) {
-                    if (g == self) continue;
-                    const uint32_t k2 = gkey[g];
-                    rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+        if (any)
+            for (int q = tid; q < ncalls; q += kThreads) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int s = q * 4 + u;
+                    if (s >= S) continue;
+                    const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
+                    if (!straddles(g0, g1)) continue;
+                    const uint32_t self = g0 + tsl[s];
+                    uint32_t rank = g0;
+                    for (uint32_t g = g0; g < g1; g++) {
+                        if (g == self) continue;
+                        const uint32_t k2 = gkey[g];
+                        rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+                    }
+                    dst[s] = cn_of(rank);
                 }
-            dst[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
-        }
+            }
         __syncthreads();
     };
 
     // ---- generate_stream_pos(g) + initialize_messages_circular(g) (BPF:1927-1932, 1149-1166) ------------------
     auto generate = [&](long long g) {
         rank_position(g + dv - 1);
+        STAMP(4);
         const int slot = (int)(g % L), cslot_new = (int)((g + dv - 1) % L);
         for (int k = tid; k < C; k += kThreads) cn[cslot_new * C + k] = 0;      // a fresh CN position (BPF:1832-1837)
         const bool doped = position_is_doped(a, g);
@@ -203,6 +252,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             if (lane == 63 && tot) atomicAdd(&scal[S_ACC], (int)tot);
         }
         __syncthreads();
+        STAMP(5);
         if (tid == 0) { pos_cnt[slot] = scal[S_ACC]; scal[S_ACC] = 0; }
         for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
             uint16_t loc[8];
@@ -228,14 +278,14 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
 
     int genq = 0;                                           // queue generation counter
     for (int step = 0; step < a.npos; step++, pos++) {
+        STAMP(0);
         const long long pd = pos - ms, pe = pos - 2 * dv + 1;
-        if (pd >= 0 && !position_is_doped(a, pd)) { gb += V; gbl += 1; }        // BPF:2017-2028
-        if (pe >= 0 && !position_is_doped(a, pe)) { gbe += V; gble += 1; }
+        if (tid == 0) {                                                         // BPF:2017-2028
+            if (pd >= 0 && !position_is_doped(a, pd)) { acc[C_GB] += V; acc[C_GBL] += 1; }
+            if (pe >= 0 && !position_is_doped(a, pe)) { acc[C_GBE] += V; acc[C_GBLE] += 1; }
+        }
 
         // ---- decodeBP_SW_circular(pos) --------------------------------------------------------------------
-        const long long vlo = pd > 0 ? pd : 0;              // VN window [vlo, pos+W)
-        int term = 0;
-        for (long long qq = vlo; qq < pos + W; qq++) term += pos_cnt[(int)(qq % L)];
         // frontier of a new window: degree-1 CNs of the position(s) that entered it
         if (tid == 0) { scal[S_PUSH + genq % 3] = 0; scal[S_OVF + genq % 3] = 0; }
         __syncthreads();
@@ -243,40 +293,50 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             uint32_t *qc = (genq & 1) ? q1 : q0;
             for (long long qq = (pos == 0 ? 0 : pos + W - 1); qq < pos + W; qq++) {
                 const int cs = (int)(qq % L) * C;
-                for (int k = tid; k < C; k += kThreads)
-                    if ((ldcn(cs + k) >> kCntShift) == 1u) {
+                for (int k = tid; k < C; k += kThreads) {
+                    const uint32_t w = ldcn(cs + k);
+                    if ((w >> kCntShift) == 1u) {                                 // the queues hold the VN to release
                         const int idx = atomicAdd(&scal[S_PUSH + genq % 3], 1);
-                        if (idx < kQCap) qc[idx] = (uint32_t)(cs + k); else scal[S_OVF + genq % 3] = 1;
+                        if (idx < kQCap) qc[idx] = w & kSumMask; else scal[S_OVF + genq % 3] = 1;
                     }
+                }
             }
         }
         __syncthreads();
+        STAMP(1);
         int ncur = min(scal[S_PUSH + genq % 3], kQCap);
         bool rescan = scal[S_OVF + genq % 3] != 0;
         const int basemod = (int)(((pos - ms) % L + L) % L);
-        int prec = L * V;
         for (;;) {
             uint32_t *qc = (genq & 1) ? q1 : q0, *qn = (genq & 1) ? q0 : q1;
             int *push_cnt = &scal[S_PUSH + (genq + 1) % 3], *push_ovf = &scal[S_OVF + (genq + 1) % 3];
-            int *rem_cnt = &scal[S_REM + genq % 3];
-            if (tid == 0) { scal[S_PUSH + (genq + 2) % 3] = 0; scal[S_OVF + (genq + 2) % 3] = 0; scal[S_REM + (genq + 1) % 3] = 0; }
-            int removed = 0;
-            auto release = [&](int c) {
-                const uint32_t w = ldcn(c);
-                if ((w >> kCntShift) != 1u) return;
-                const int j = (int)(w & kSumMask), slot_j = j / V, t = j - slot_j * V;
+            if (tid == 0) { scal[S_PUSH + (genq + 2) % 3] = 0; scal[S_OVF + (genq + 2) % 3] = 0; }
+            // Release VN j, the lone erased neighbour of some window CN.  A level costs two dependent trips to the L2
+            // instead of four: the queue names the VN (a CN whose count drops 2 -> 1 is left with Σ ids − j: no read of the
+            // CN word next round), and the VN's row is fetched beside the claim of its S bit, not after it.  The claim is
+            // the guard: an entry whose VN was released meanwhile (by another CN, or named twice) finds the bit clear.
+            // (Letting a thread follow its chain past the barrier was tried: one thread then walks what a round spreads
+            // over the workgroup — 1.75 times the time.)
+            auto release = [&](int j) {
+                const int slot_j = j / V, t = j - slot_j * V;
                 const uint32_t bit = 1u << (t & 31);
+                uint16_t loc[8];
+                if (dv == 4) {
+                    const uint2 r = *reinterpret_cast<const uint2 *>(adj + (size_t)j * 4);
+                    loc[0] = (uint16_t)r.x; loc[1] = (uint16_t)(r.x >> 16); loc[2] = (uint16_t)r.y; loc[3] = (uint16_t)(r.y >> 16);
+                } else {
+                    for (int i = 0; i < dv; i++) loc[i] = adj[(size_t)j * dv + i];
+                }
                 if (!(atomicAnd(&Sb[slot_j * wpp + (t >> 5)], ~bit) & bit)) return;
-                removed++;
                 atomicSub(&pos_cnt[slot_j], 1);
                 const long long qj = pos - ms + ((slot_j - basemod + L) % L);     // absolute position of VN j
                 for (int i = 0; i < dv; i++) {
                     const long long qc2 = qj + i;
-                    const int c2 = (int)(qc2 % L) * C + adj[(size_t)j * dv + i];
-                    const uint32_t o = atomicSub(&cn[c2], kCntOne + (uint32_t)j) >> kCntShift;
-                    if (o == 2u && qc2 >= pos && qc2 < pos + W) {                  // a window CN is left with one VN
+                    const int c2 = (int)(qc2 % L) * C + loc[i];
+                    const uint32_t old = atomicSub(&cn[c2], kCntOne + (uint32_t)j);
+                    if ((old >> kCntShift) == 2u && qc2 >= pos && qc2 < pos + W) { // a window CN is left with one VN
                         const int idx = atomicAdd(push_cnt, 1);
-                        if (idx < kQCap) qn[idx] = (uint32_t)c2; else *push_ovf = 1;
+                        if (idx < kQCap) qn[idx] = (old & kSumMask) - (uint32_t)j; else *push_ovf = 1;
                     }
                 }
             };
@@ -286,23 +346,21 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
                 // fixpoint and only the fixpoint is observable)
                 for (long long qq = pos; qq < pos + W; qq++) {
                     const int cs = (int)(qq % L) * C;
-                    for (int k = tid; k < C; k += kThreads) release(cs + k);
+                    for (int k = tid; k < C; k += kThreads) {
+                        const uint32_t w = ldcn(cs + k);
+                        if ((w >> kCntShift) == 1u) release((int)(w & kSumMask));
+                    }
                 }
             } else {
                 for (int k = tid; k < ncur; k += kThreads) release((int)qc[k]);
             }
-            {
-                const uint32_t tot = wave_inclusive_scan((uint32_t)removed);
-                if (lane == 63 && tot) atomicAdd(rem_cnt, (int)tot);
-            }
             __syncthreads();
-            term -= *rem_cnt;
             rescan = *push_ovf != 0;
             ncur = min(*push_cnt, kQCap);
             genq++;
-            if (term == 0 || term == prec) break;                                 // BPF:1454-1455
-            prec = term;
+            if (ncur == 0 && !rescan) break;                                      // nothing left to fire (BPF:1454-1455)
         }
+        STAMP(2);
         // decision on position pos-ms (BPF:1445-1449), VNerased := S there
         int nep = 0;
         if (pd >= 0) {
@@ -310,8 +368,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             nep = pos_cnt[slot];
             for (int w = tid; w < wpp; w += kThreads) Eb[slot * wpp + w] = Sb[slot * wpp + w];
         }
-        ne += nep;
-        if (nep > 0) be += 1;                                                      // BPF:1480-1483
+        if (tid == 0) { acc[C_NE] += nep; if (nep > 0) acc[C_BE] += 1; }           // BPF:1480-1483
         __syncthreads();
         // size-2 stopping-set expurgation of position pos-2dv+1 (get_deg_two_ss, BPF:1227-1283, 1485-1497)
         if (pe >= 0) {
@@ -340,40 +397,38 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             const int cexp = scal[S_ACC];
             __syncthreads();
             if (tid == 0) scal[S_ACC] = 0;
-            if (cexp > 0) { ee += cexp; bee += 1; }
+            if (tid == 0 && cexp > 0) { acc[C_EE] += cexp; acc[C_BEE] += 1; }
         }
         if (a.trace && tid == 0) {
             int32_t *tr = a.trace + ((size_t)blockIdx.x * a.npos + step) * 10;
-            tr[0] = (int32_t)pos; tr[1] = nep; tr[2] = (int32_t)ne; tr[3] = (int32_t)be; tr[4] = (int32_t)ee; tr[5] = (int32_t)bee;
-            tr[6] = (int32_t)gb; tr[7] = (int32_t)gbl; tr[8] = (int32_t)gbe; tr[9] = (int32_t)gble;
+            tr[0] = (int32_t)pos; tr[1] = nep;
+            tr[2] = (int32_t)acc[C_NE]; tr[3] = (int32_t)acc[C_BE]; tr[4] = (int32_t)acc[C_EE]; tr[5] = (int32_t)acc[C_BEE];
+            tr[6] = (int32_t)acc[C_GB]; tr[7] = (int32_t)acc[C_GBL]; tr[8] = (int32_t)acc[C_GBE]; tr[9] = (int32_t)acc[C_GBLE];
         }
         __syncthreads();
+        STAMP(3);
         generate(gen); gen++;                                                      // BPF:2036-2045
+        STAMP(6);
     }
+    STAMP_FLUSH();
 
     __syncthreads();
     for (int i = tid; i < L; i += kThreads) pos_cnt_g[i] = pos_cnt[i];
     if (tid == 0) {
-        cnt64[C_NE] = ne; cnt64[C_BE] = be; cnt64[C_EE] = ee; cnt64[C_BEE] = bee;
-        cnt64[C_GB] = gb; cnt64[C_GBL] = gbl; cnt64[C_GBE] = gbe; cnt64[C_GBLE] = gble;
+        for (int k = C_NE; k <= C_GBLE; k++) cnt64[k] = acc[k];
         cnt64[C_POS] = pos; cnt64[C_GEN] = gen;
         if (a.counters_out) {
             long long *o = a.counters_out + (size_t)blockIdx.x * 10;
-            o[0] = ne; o[1] = be; o[2] = ee; o[3] = bee; o[4] = gb; o[5] = gbl; o[6] = gbe; o[7] = gble; o[8] = pos; o[9] = gen;
+            for (int k = C_NE; k <= C_GBLE; k++) o[k] = acc[k];
+            o[8] = pos; o[9] = gen;
         }
     }
 }
 
 template <int ROWS>
-__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_bp_kernel_two_per_cu(const Args a)
+__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_bp_kernel(const Args a)
 {
-    stream_bp_body<ROWS, kQCapTwo>(a);
-}
-
-template <int ROWS>
-__global__ __launch_bounds__(kThreads) void stream_bp_kernel(const Args a)
-{
-    stream_bp_body<ROWS, kQCapOne>(a);
+    stream_bp_body<ROWS>(a);
 }
 
 
@@ -389,7 +444,7 @@ int make_state_layout(const scldpc_code_params *p, StateLayout *lay)
     lay->ebits = take(L * lay->wpp * 4);
     lay->cn = take(L * C * 4);
     lay->poscnt = take(L * 4);
-    lay->tk = take(S * 4); lay->gkey = take(S * 4); lay->tslot = take(S * 2); lay->gidx = take(S * 2);
+    lay->gkey = take(S * 4); lay->gidx = take(S * 2);
     lay->counters = take(C_NCOUNT * 8);
     lay->total = off;
     return 0;
@@ -403,7 +458,7 @@ int check_stream(const scldpc_code_params *p, int W, const char *who)
     // the stream is generated L/2 positions ahead (BPF:2001): the window and the CNs of its VNs must exist already
     if (W < 1 || W + p->dv - 1 > p->L / 2)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: need 1 <= W and W + dv - 1 <= L/2 (W=%d, L=%d)", who, W, p->L);
-    if ((int64_t)p->cns_pos * p->dc > 65536 || p->dc > 15 || p->dv > 8 ||
+    if ((int64_t)p->cns_pos * p->dc > 65535 || p->dc > 15 || p->dv > 8 ||
         (int64_t)p->dc * p->L * p->vns_pos >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: ensemble too large for the streaming kernel", who);
     return SCLDPC_OK;
@@ -457,9 +512,11 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
     a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos;
     const int rows = a.nb / kThreads;
-    const size_t lds_bytes = 4u * ((size_t)a.nb + 2 * (rows <= 4 ? kQCapTwo : kQCapOne) + 32 + kWaves * kWaves + kMaxL + S_NSCAL);
-    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel_two_per_cu<1> : rows == 2 ? stream_bp_kernel_two_per_cu<2>
-                               : rows == 4 ? stream_bp_kernel_two_per_cu<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
+    const size_t lds_bytes = 4u * ((size_t)a.nb / 2 + 2 * kQCap + 32 + kMaxL + S_NSCAL + 2 * 8) + (((size_t)a.S + 15) & ~(size_t)15);
+    if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_bytes);
+    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel<1> : rows == 2 ? stream_bp_kernel<2>
+                               : rows == 4 ? stream_bp_kernel<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);

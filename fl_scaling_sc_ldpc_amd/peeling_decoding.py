@@ -241,10 +241,12 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
 
 def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_protograph, num_repeats=None,
                                   doping_points=[], rng="numpy", seed=0, batch=None, device=None,
-                                  want_moments=False):
+                                  want_moments=False, moments_from="auto"):
     """Random-pick peeling with the degree-1-CN trajectory (PD:705-789): returns (None, r1, plrs) with
     r1 int64 [num_repeats, num_pd_steps+1] and plrs float64 [num_repeats].  want_moments=True (philox mode) returns
-    (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories.
+    (None, moments int64 [3, num_pd_steps+1], plrs) instead of the full trajectories; moments_from: "rows" (the batch's
+    trajectories stay on the device and one pass reduces them), "kernel" (three atomics per step inside the pick chain, no
+    row buffer) or "auto" (rows where they fit 24 GB).
     rng="philox" under torch.distributed: rank r runs a contiguous share of the trials (global trial indices, so the
     draws do not depend on the sharding); one all-reduce sums the moment vectors (24 B per step) and fills in plrs —
     and the r1 rows when they are asked for — so every rank returns what a single rank would."""
@@ -295,8 +297,17 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
         nb = min(batch, offs[rank + 1] - done)
         d_adj, d_ch = E.sample_philox(p, seed, done, nb, e, list(doping_points), device=device,
                                       adj16=not is_protograph, ensemble="protograph" if is_protograph else "olmos")
+        # moments: three global atomics per step inside the pick chain cost 7 % (tools/ab_c3.py); where the batch's rows fit
+        # (4 B per step and trial) they are written instead and reduced by one pass of r1_moments
+        if moments_from not in ("auto", "rows", "kernel"):
+            raise ValueError("moments_from must be 'auto', 'rows' or 'kernel'")
+        rows_first = want_moments and (moments_from == "rows" or
+                                       (moments_from == "auto" and 4 * (num_pd_steps + 1) * nb <= 24e9))
         res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done,
-                          want_r1=not want_moments, moments=moments)
+                          want_r1=not want_moments or rows_first, moments=None if rows_first else moments)
+        if rows_first:
+            E.r1_moments(res["r1"], moments)
+            res["r1"] = None
         o = res["out"].cpu().numpy()
         plrs[done:done + nb] = (o[:, 0] - o[:, 1]) / total_generated
         if not want_moments:

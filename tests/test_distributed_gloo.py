@@ -189,8 +189,17 @@ def _fake_engine(PD):
             moments[2] += (r1 * r1).sum(0)
         return {"out": out, "r1": r1.to(torch.int32) if want_r1 else None, "moments": moments}
 
+    def r1_moments(d_r1, moments=None):
+        r = d_r1.to(torch.int64)
+        if moments is None:
+            moments = torch.zeros((3, r.shape[1]), dtype=torch.int64)
+        moments[0] += (r != 0).sum(0)
+        moments[1] += r.sum(0)
+        moments[2] += (r * r).sum(0)
+        return moments
+
     PD.E = types.SimpleNamespace(sample_philox=sample_philox, peel_sweep=peel_sweep, peel_pick=peel_pick,
-                                 CodeParams=PD.E.CodeParams)
+                                 r1_moments=r1_moments, CodeParams=PD.E.CodeParams)
 
 
 def _pd_worker(rank, world, port, q):
@@ -210,6 +219,9 @@ def _pd_worker(rank, world, port, q):
                                                    device="cpu")
     _, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(0.45, 4, 8, 10, 20, False, False, 11, [], rng="philox", seed=3, batch=3,
                                                      device="cpu", want_moments=True)
+    _, mom_k, _ = PD.simulate_peeling_decoder_ldpc(0.45, 4, 8, 10, 20, False, False, 11, [], rng="philox", seed=3, batch=3,
+                                                   device="cpu", want_moments=True, moments_from="kernel")
+    assert (mom_k == mom).all()                            # rows + reduction pass == accumulation inside the kernel
     q.put((rank, out, r1.tolist(), plrs.tolist(), mom.tolist(), plrs2.tolist()))
     if world > 1:
         dist.barrier()

@@ -188,7 +188,10 @@ def test_peel_pick_beyond_the_lds_budget(PD, oracle, L, M, e, term):
     T = 3
     none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=8)
     none, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=8,
-                                                        want_moments=True, batch=2)
+                                                        want_moments=True, batch=2, moments_from="kernel")
+    none, mom_rows, plrs3 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=8,
+                                                             want_moments=True, batch=2)
+    assert (mom_rows == mom).all() and (plrs3 == plrs2).all()           # rows + one reduction pass == atomics in the chain
     p = E.CodeParams(4, 8, L, M // 2, M)
     d_adj, d_ch = E.sample_philox(p, 8, 0, T, e, adj16=True)
     A = E.adj16_to_global(p, d_adj.cpu().numpy()).astype(np.int64)
@@ -327,7 +330,10 @@ def test_config3_full_size_random_pick_equals_cpu_twin(PD, oracle, term, e, seed
     L, M, T = 50, 10000, 3
     none, r1, plrs = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=seed)
     none, mom, plrs2 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=seed,
-                                                        want_moments=True, batch=2)
+                                                        want_moments=True, batch=2, moments_from="kernel")
+    none, mom_rows, plrs3 = PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=seed,
+                                                             want_moments=True, batch=2, moments_from="rows")
+    assert (mom_rows == mom).all() and (plrs3 == plrs2).all()
     assert r1.shape == (T, int(M * (L + 3 if term else L) * (e + 0.1)) + 1)
     p = E.CodeParams(4, 8, L, M // 2, M)
     d_adj, d_ch = E.sample_philox(p, seed, 0, T, e, adj16=True)

@@ -43,5 +43,17 @@ a2, cn2, ch2 = E.sample_philox_cn16(p, 1, 0, T, 0.48)
 show("sample_philox_v2_kernel", ["emit(prev)", "keys+histogram", "scan", "classify", "rank+stage+clear", "emit", "channel"])
 out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
+if "--stream" in sys.argv:                      # BASELINE config 5: where does a decoded position's time go?
+    ps = E.make_params(4, 8, 50, 5000)
+    NS = 512
+    buf = torch.zeros((NS, 16), dtype=torch.int64, device="cuda")
+    assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
+    st = E.Streams(ps, NS, seed=1, eps=0.485, W=20, doped=(10, 11, 12))
+    st.run(16)
+    torch.cuda.synchronize()
+    buf.zero_()
+    st.run(16)
+    show("stream_bp_kernel (16 positions)", ["(loop top)", "window frontier", "window rounds", "decision + expurgation",
+                                             "generate: permutation ranking", "generate: channel", "generate: wiring"])
 it = out["counters"][:, 5].float().mean().item()
 print("mean iterations", it)
