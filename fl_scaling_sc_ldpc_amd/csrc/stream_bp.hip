@@ -30,10 +30,10 @@ using namespace scldpc_dev;
 constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kMaxL = 256;
 constexpr int kQCap = 2048;                         // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
-enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_NSCAL = 16 };
+enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
-    size_t adj, inter, sbits, ebits, cn, poscnt, gkey, gidx, counters, total;
+    size_t adj, inter, sbits, ebits, cn, poscnt, gkey, wlist, counters, total;
     int wpp;                // 32-bit words of S / VNerased per position
 };
 
@@ -90,8 +90,8 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
     uint32_t *Eb = reinterpret_cast<uint32_t *>(st + a.lay.ebits);         // [L][wpp] VNerased
     uint32_t *cn = reinterpret_cast<uint32_t *>(st + a.lay.cn);            // [L*C]
     int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
-    uint32_t *gkey = reinterpret_cast<uint32_t *>(st + a.lay.gkey);       // [S] keys of straddling buckets, by rank slot
-    uint16_t *gidx = reinterpret_cast<uint16_t *>(st + a.lay.gidx);       // [S] and their sockets
+    uint2 *gkey = reinterpret_cast<uint2 *>(st + a.lay.gkey);             // [S] (key, socket) of straddling buckets' keys, by rank slot
+    uint2 *wlist = reinterpret_cast<uint2 *>(st + a.lay.wlist);           // [S] the same keys as a dense list: (key, socket | first rank << 16)
     long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
     const unsigned long long sid = a.sid0 + blockIdx.x;
     const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
@@ -118,6 +118,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         // except the straddling buckets' keys, which are grouped in the stream's blob (3-15 % of the sockets).
         const int ncalls = (S + 3) / 4;
         for (int b = tid; b < a.nb / 2; b += kThreads) hist[b] = 0;
+        if (tid == 0) scal[S_WL] = 0;
         __syncthreads();
         uint32_t crowded = 0;
         for (int q = tid; q < ncalls; q += kThreads) {
@@ -136,6 +137,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         }
         if (crowded >= 256u) __builtin_trap();              // arrival slots are kept in a byte (a bucket holds 1-4 keys on average)
         __syncthreads();
+        STAMP(7);
         // wave w scans buckets [w, w+1) * nb/16 = ROWS * 32 words of two counters: exclusive prefix inside the chunk, then
         // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits (S <= 65535)
         constexpr int R2 = ROWS >= 2 ? ROWS / 2 : 1;
@@ -166,6 +168,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
                 if (on) hist[w0 + r * 64] += base * 0x10001u;   // both halves stay below 65536: no carry between them
         }
         __syncthreads();
+        STAMP(8);
         auto bucket_base = [&](uint32_t b) -> uint32_t {
             return b >= (uint32_t)a.nb ? (uint32_t)S : (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
         };
@@ -177,7 +180,6 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         };
         auto cn_of = [&](uint32_t rank) { return (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc); };
         uint16_t *dst = inter + (size_t)(cpos % dv) * S;
-        bool any = false;
         for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
             philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
@@ -189,8 +191,8 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
                 const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
                 if (!straddles(g0, g1)) { c4[u] = cn_of(g0); continue; }
                 const uint32_t at = g0 + tsl[s];
-                gkey[at] = k; gidx[at] = (uint16_t)s;
-                any = true;
+                gkey[at] = make_uint2(k, (uint32_t)s);
+                wlist[atomicAdd(&scal[S_WL], 1)] = make_uint2(k, (uint32_t)s | (g0 << 16));
             }
             if (q * 4 + 3 < S && (S & 3) == 0) {
                 *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
@@ -199,26 +201,27 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             }
         }
         __syncthreads();
-        if (any)
-            for (int q = tid; q < ncalls; q += kThreads) {
-                uint32_t r[4];
-                philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+        STAMP(9);
+        // the straddlers as a dense list: a wave that met them where they stand would stop at nearly every key for a
+        // trip to the L2 (14 % of the lanes, 20 keys per lane: 20 % of a position's time); here every lane has one
+        {
+            const int nwl = scal[S_WL];
+            for (int w = tid; w < nwl; w += kThreads) {
+                const uint2 e = wlist[w];
+                const uint32_t k = e.x, s = e.y & 0xFFFFu, g0 = e.y >> 16, g1 = bucket_base((k >> a.shift) + 1u);
+                // rank among the bucket mates: their records are fetched four at a time (independent loads in flight),
+                // a key's own record compares false with itself
+                uint32_t rank = g0;
+                for (uint32_t g = g0; g < g1; g += 4) {
+                    uint2 m[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int s = q * 4 + u;
-                    if (s >= S) continue;
-                    const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
-                    if (!straddles(g0, g1)) continue;
-                    const uint32_t self = g0 + tsl[s];
-                    uint32_t rank = g0;
-                    for (uint32_t g = g0; g < g1; g++) {
-                        if (g == self) continue;
-                        const uint32_t k2 = gkey[g];
-                        rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
-                    }
-                    dst[s] = cn_of(rank);
+                    for (int i = 0; i < 4; i++) m[i] = g + i < g1 ? gkey[g + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
                 }
+                dst[s] = cn_of(rank);
             }
+        }
         __syncthreads();
     };
 
@@ -444,7 +447,7 @@ int make_state_layout(const scldpc_code_params *p, StateLayout *lay)
     lay->ebits = take(L * lay->wpp * 4);
     lay->cn = take(L * C * 4);
     lay->poscnt = take(L * 4);
-    lay->gkey = take(S * 4); lay->gidx = take(S * 2);
+    lay->gkey = take(S * 8); lay->wlist = take(S * 8);
     lay->counters = take(C_NCOUNT * 8);
     lay->total = off;
     return 0;

@@ -54,6 +54,7 @@ if "--stream" in sys.argv:                      # BASELINE config 5: where does 
     buf.zero_()
     st.run(16)
     show("stream_bp_kernel (16 positions)", ["(loop top)", "window frontier", "window rounds", "decision + expurgation",
-                                             "generate: permutation ranking", "generate: channel", "generate: wiring"])
+                                             "generate: ranking (straddlers + rest)", "generate: channel", "generate: wiring",
+                                             "ranking: draw + count", "ranking: scan", "ranking: classify"])
 it = out["counters"][:, 5].float().mean().item()
 print("mean iterations", it)
