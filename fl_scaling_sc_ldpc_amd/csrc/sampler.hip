@@ -310,53 +310,79 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     STAMP_FLUSH();
 }
 
-// Large ensembles (more than 8192 sockets per position, e.g. N = 5000 / 10000): same keys, same ranking, but the
-// per-socket scratch (keys, arrival slots, grouped keys, the ring of dv permutations) lives in a per-trial slice of
-// the library workspace (L2-resident) instead of LDS / registers; only the bucket counters stay in LDS.
-struct BigScratch { uint32_t *tk, *gkey; uint16_t *tslot, *gidx, *win; };
-
+// Ensembles beyond 8192 sockets per position (the notebook's N = 10000 is 40000): the bucket counters (16 bits, two per
+// word: every bucket's first rank after the scan), the sockets' arrival slots (one byte each) stay in LDS — 72 KB at
+// S = 40000, two workgroups per CU — and the keys are drawn again by each of the three passes instead of being stored
+// (Philox is pure VALU).  Only the keys of straddling buckets (stream_bp.hip has the same ranking) and the ring of dv
+// permutations live in a per-trial slice of the caller's workspace (L2-resident): the straddlers are ranked from a dense
+// worklist, one trip to the L2 per lane, not one per key and wave.
 template <int ROWS, bool ADJ16>
-__global__ __launch_bounds__(kThreads) void sample_philox_big_kernel(const SArgs a, char *ws, size_t ws_stride)
+__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_big_kernel(const SArgs a, char *ws, size_t ws_stride)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *hist = lds;
-    uint32_t *wsum = lds + a.off_wsum;
-    uint32_t *wpre = wsum + 32;
+    uint32_t *hist = lds;                                               // nb / 2 words
+    uint32_t *wsum = lds + a.off_wsum;                                  // 16 wave totals, [16] = worklist length
+    uint8_t *tsl = reinterpret_cast<uint8_t *>(wsum + 32);              // [S]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long trial = a.trial0 + blockIdx.x;
     const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     const int S = a.S, nb = a.nb, dv = a.dv, ncalls = (S + 3) >> 2;
     char *base = ws + (size_t)blockIdx.x * ws_stride;
-    uint32_t *tk = reinterpret_cast<uint32_t *>(base);
-    uint32_t *gkey = tk + S;
-    uint16_t *tslot = reinterpret_cast<uint16_t *>(gkey + S);
-    uint16_t *gidx = tslot + S;
-    uint16_t *win = gidx + S;                                       // dv * S
+    uint2 *gkey = reinterpret_cast<uint2 *>(base);                      // [S] (key, socket) of straddling buckets' keys, by rank slot
+    uint2 *wlist = gkey + S;                                            // [S] the same as a dense list: (key, socket | first rank << 16)
+    uint16_t *win = reinterpret_cast<uint16_t *>(wlist + S);            // [dv][S] CN-local id of every socket, by CN position % dv
+    auto cn_of = [&](uint32_t rank) { return a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc; };
+    auto bucket_base = [&](uint32_t b) -> uint32_t {
+        return b >= (uint32_t)nb ? (uint32_t)S : (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
+    };
+    // one past the last rank of a non-empty bucket that starts at g0: the next bucket's first rank, which as 16 bits reads
+    // 0 instead of 65536 when S = 65536 and only empty buckets follow
+    auto bucket_end = [&](uint32_t b, uint32_t g0) -> uint32_t {
+        const uint32_t g1 = bucket_base(b + 1u);
+        return g1 < g0 ? g1 + 0x10000u : g1;
+    };
+    // CN = rank / dc: only buckets whose ranks straddle a multiple of dc need their keys ordered (sampler_v2.hip)
+    auto straddles = [&](uint32_t g0, uint32_t g1) {
+        return g1 - g0 > 1u && (a.dc_shift >= 0 ? (g0 >> a.dc_shift) != ((g1 - 1u) >> a.dc_shift)
+                                                : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
+    };
 
     for (int p = 0; p < a.D; p++) {
-        for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
+        for (int b = tid; b < nb / 2; b += kThreads) hist[b] = 0;
+        if (tid == 0) wsum[kWaves] = 0;
         __syncthreads();
+        uint32_t crowded = 0;
         for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
             philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int s = q * 4 + u;
-                if (s < S) { tk[s] = r[u]; tslot[s] = (uint16_t)atomicAdd(&hist[r[u] >> a.shift], 1u); }
+                if (s < S) {
+                    const uint32_t b = r[u] >> a.shift, sh = (b & 1u) * 16u;
+                    const uint32_t sl = (atomicAdd(&hist[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                    tsl[s] = (uint8_t)sl;
+                    crowded |= sl;
+                }
             }
         }
+        if (crowded >= 256u) __builtin_trap();              // arrival slots are kept in a byte (a bucket holds 1-4 keys on average)
         __syncthreads();
+        // wave w scans buckets [w, w+1) * nb/16 = ROWS * 32 words of two counters: exclusive prefix inside the chunk, then
+        // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits
+        constexpr int R2 = ROWS / 2;
+        const int w0 = wave * (ROWS * 32) + lane;
         {
-            const int b0 = wave * (ROWS * 64) + lane;
-            uint32_t v[ROWS], inc[ROWS];
+            uint32_t v[R2], ps[R2], inc[R2];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) v[r] = hist[b0 + r * 64];
+            for (int r = 0; r < R2; r++) { v[r] = hist[w0 + r * 64]; ps[r] = (v[r] & 0xFFFFu) + (v[r] >> 16); }
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) inc[r] = wave_inclusive_scan(v[r]);
+            for (int r = 0; r < R2; r++) inc[r] = wave_inclusive_scan(ps[r]);
             uint32_t carry = 0;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                hist[b0 + r * 64] = carry + inc[r] - v[r];
+            for (int r = 0; r < R2; r++) {
+                const uint32_t ex = carry + inc[r] - ps[r];
+                hist[w0 + r * 64] = (ex & 0xFFFFu) | ((ex + (v[r] & 0xFFFFu)) << 16);
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
             }
             if (lane == 0) wsum[wave] = carry;
@@ -365,43 +391,64 @@ __global__ __launch_bounds__(kThreads) void sample_philox_big_kernel(const SArgs
         {
             const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
             const uint32_t inc = wave_inclusive_scan(t);
-            if (lane < kWaves) wpre[wave * kWaves + lane] = inc - t;
-        }
-        auto bucket_base = [&](uint32_t b) -> uint32_t {
-            return b >= (uint32_t)nb ? (uint32_t)S : hist[b] + wpre[wave * kWaves + (b >> a.lgchunk)];
-        };
-        // CN = rank / dc: only buckets whose ranks straddle a multiple of dc need their keys ordered (sampler_v2.hip)
-        auto straddles = [&](uint32_t g0, uint32_t g1) {
-            return g1 - g0 > 1u && (a.dc_shift >= 0 ? (g0 >> a.dc_shift) != ((g1 - 1u) >> a.dc_shift)
-                                                    : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
-        };
-        for (int s = tid; s < S; s += kThreads) {
-            const uint32_t k = tk[s], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
-            if (straddles(g0, g1)) { gkey[g0 + tslot[s]] = k; gidx[g0 + tslot[s]] = (uint16_t)s; }
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(inc - t), wave);
+#pragma unroll
+            for (int r = 0; r < R2; r++) {                                  // (a first rank of 65536 = S wraps to 0: see bucket_end)
+                const uint32_t w = hist[w0 + r * 64];
+                hist[w0 + r * 64] = ((w + before) & 0xFFFFu) | (((w >> 16) + before) << 16);
+            }
         }
         __syncthreads();
         uint16_t *wp = win + (size_t)(p % dv) * S;
-        for (int s = tid; s < S; s += kThreads) {
-            const uint32_t k = tk[s], b = k >> a.shift;
-            const uint32_t g0 = bucket_base(b), g1 = bucket_base(b + 1), self = g0 + tslot[s];
-            uint32_t rank = g0;
-            if (straddles(g0, g1))
-                for (uint32_t g = g0; g < g1; g++) {
-                    if (g == self) continue;
-                    const uint32_t k2 = gkey[g];
-                    rank += (k2 < k) || (k2 == k && gidx[g] < (uint16_t)s);
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4], c4[4] = {0, 0, 0, 0};            // (a straddler's entry is written from the worklist)
+            philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, a.seed_lo, a.seed_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s >= S) continue;
+                const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_end(b, g0);
+                if (!straddles(g0, g1)) { c4[u] = cn_of(g0); continue; }
+                gkey[g0 + tsl[s]] = make_uint2(k, (uint32_t)s);
+                wlist[atomicAdd(&wsum[kWaves], 1u)] = make_uint2(k, (uint32_t)s | (g0 << 16));
+            }
+            if (q * 4 + 3 < S && (S & 3) == 0) {
+                *reinterpret_cast<uint2 *>(wp + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
+            } else {
+                for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[q * 4 + u] = (uint16_t)c4[u];
+            }
+        }
+        __syncthreads();
+        {
+            const int nwl = (int)wsum[kWaves];
+            for (int w = tid; w < nwl; w += kThreads) {
+                const uint2 e = wlist[w];
+                const uint32_t k = e.x, s = e.y & 0xFFFFu, g0 = e.y >> 16, g1 = bucket_end(k >> a.shift, g0);
+                uint32_t rank = g0;                                     // mates fetched four at a time; a key's own record
+                for (uint32_t g = g0; g < g1; g += 4) {                 // compares false with itself
+                    uint2 m[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) m[i] = g + i < g1 ? gkey[g + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
                 }
-            wp[s] = (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc);
+                wp[s] = (uint16_t)cn_of(rank);
+            }
         }
         __syncthreads();
         const int qpos = p - (dv - 1);
         if (qpos >= 0) {
             for (int t = tid; t < a.vns_pos; t += kThreads) {
                 const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
-                for (int i = 0; i < dv; i++) {
-                    const uint32_t l = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
-                    if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l;
-                    else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l;
+                uint32_t l[8];
+                for (int i = 0; i < dv; i++) l[i] = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                if (ADJ16 && dv == 4) {
+                    *reinterpret_cast<uint2 *>(a.vn_adj16 + j * 4) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                } else {
+                    for (int i = 0; i < dv; i++) {
+                        if (ADJ16) a.vn_adj16[j * dv + i] = (uint16_t)l[i];
+                        else       a.vn_adj[j * dv + i] = (qpos + i) * a.cns_pos + (int)l[i];
+                    }
                 }
             }
         }
@@ -483,13 +530,13 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         if (c < x) c += 1.0;
         a.thresh = (uint32_t)c;
     }
-    int off = (a.nb + 3) & ~3;
+    int off = big ? a.nb / 2 : (a.nb + 3) & ~3;
     if (!big) {
         a.off_gkey = off; off += (a.S + 3) & ~3;
         a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
         a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
     }
-    a.off_wsum = off; off += 32 + kWaves * kWaves;
+    a.off_wsum = off; off += big ? 32 + (a.S + 15) / 16 * 4 : 32 + kWaves * kWaves;
     const size_t lds_bytes = 4u * (size_t)off;
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: needs %zu B of LDS", who, lds_bytes);
@@ -498,7 +545,7 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
     a.chan = d_chan_bits;
 
     if (big) {
-        const size_t stride = (((size_t)a.S * (12 + 2 * p->dv)) + 255) & ~(size_t)255;
+        const size_t stride = (((size_t)a.S * (16 + 2 * p->dv)) + 255) & ~(size_t)255;
         if (scratch.query) { *scratch.query = stride * (size_t)ntrials; return SCLDPC_OK; }
         void *ws = nullptr;
         if (int rc = scldpc::take_scratch(who, scratch, stride * (size_t)ntrials, &ws)) return rc;

@@ -139,7 +139,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         __syncthreads();
         STAMP(7);
         // wave w scans buckets [w, w+1) * nb/16 = ROWS * 32 words of two counters: exclusive prefix inside the chunk, then
-        // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits (S <= 65535)
+        // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits
         constexpr int R2 = ROWS >= 2 ? ROWS / 2 : 1;
         const bool on = ROWS >= 2 || lane < 32;
         const int w0 = wave * (ROWS * 32) + lane;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
 #pragma unroll
             for (int r = 0; r < R2; r++) {
                 const uint32_t ex = carry + inc[r] - ps[r];
-                if (on) hist[w0 + r * 64] = ex | ((ex + (v[r] & 0xFFFFu)) << 16);
+                if (on) hist[w0 + r * 64] = (ex & 0xFFFFu) | ((ex + (v[r] & 0xFFFFu)) << 16);
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
             }
             if (lane == 0) wsum[wave] = carry;
@@ -165,12 +165,21 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(inc - t), wave);
 #pragma unroll
             for (int r = 0; r < R2; r++)
-                if (on) hist[w0 + r * 64] += base * 0x10001u;   // both halves stay below 65536: no carry between them
+                if (on) {                                   // (a first rank of 65536 = S wraps to 0: see bucket_end)
+                    const uint32_t w = hist[w0 + r * 64];
+                    hist[w0 + r * 64] = ((w + base) & 0xFFFFu) | (((w >> 16) + base) << 16);
+                }
         }
         __syncthreads();
         STAMP(8);
         auto bucket_base = [&](uint32_t b) -> uint32_t {
             return b >= (uint32_t)a.nb ? (uint32_t)S : (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
+        };
+        // one past the last rank of a non-empty bucket that starts at g0: the next bucket's first rank, which as 16 bits
+        // reads 0 instead of 65536 when S = 65536 and only empty buckets follow
+        auto bucket_end = [&](uint32_t b, uint32_t g0) -> uint32_t {
+            const uint32_t g1 = bucket_base(b + 1u);
+            return g1 < g0 ? g1 + 0x10000u : g1;
         };
         // CN = rank / dc, so a bucket whose ranks [g0, g1) lie inside one block of dc ranks gives all its keys the same CN
         // whatever their order: only the keys of buckets that straddle a multiple of dc are grouped and compared.
@@ -188,7 +197,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             for (int u = 0; u < 4; u++) {
                 const int s = q * 4 + u;
                 if (s >= S) continue;
-                const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_base(b + 1);
+                const uint32_t k = r[u], b = k >> a.shift, g0 = bucket_base(b), g1 = bucket_end(b, g0);
                 if (!straddles(g0, g1)) { c4[u] = cn_of(g0); continue; }
                 const uint32_t at = g0 + tsl[s];
                 gkey[at] = make_uint2(k, (uint32_t)s);
@@ -208,7 +217,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             const int nwl = scal[S_WL];
             for (int w = tid; w < nwl; w += kThreads) {
                 const uint2 e = wlist[w];
-                const uint32_t k = e.x, s = e.y & 0xFFFFu, g0 = e.y >> 16, g1 = bucket_base((k >> a.shift) + 1u);
+                const uint32_t k = e.x, s = e.y & 0xFFFFu, g0 = e.y >> 16, g1 = bucket_end(k >> a.shift, g0);
                 // rank among the bucket mates: their records are fetched four at a time (independent loads in flight),
                 // a key's own record compares false with itself
                 uint32_t rank = g0;
@@ -461,7 +470,7 @@ int check_stream(const scldpc_code_params *p, int W, const char *who)
     // the stream is generated L/2 positions ahead (BPF:2001): the window and the CNs of its VNs must exist already
     if (W < 1 || W + p->dv - 1 > p->L / 2)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: need 1 <= W and W + dv - 1 <= L/2 (W=%d, L=%d)", who, W, p->L);
-    if ((int64_t)p->cns_pos * p->dc > 65535 || p->dc > 15 || p->dv > 8 ||
+    if ((int64_t)p->cns_pos * p->dc > 65536 || p->dc > 15 || p->dv > 8 ||
         (int64_t)p->dc * p->L * p->vns_pos >= (1ll << kDegShift))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: ensemble too large for the streaming kernel", who);
     return SCLDPC_OK;
