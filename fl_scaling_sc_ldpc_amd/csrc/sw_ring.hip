@@ -72,8 +72,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
     const uint32_t *ch = a.chan + (size_t)trial * a.nw;
     uint32_t *eout = a.erased_out ? a.erased_out + (size_t)trial * a.nw : nullptr;
 
-    auto cslot = [&](int p) { return (p % R) * Cw; };                     // word base of CN position p
-    auto sslot = [&](int qq) { return (qq % RV) * wpp; };                 // word base of VN position qq
+    // Ring slots without a division (a release would pay a dozen of them): every position touched while the window
+    // stands at pw lies within [pw - (dv-1), pw + W + dv - 1], less than a ring apart, so one wrap of pw's own slot does.
+    int pw = 0, cb = 0, vb = 0;                                           // window position, pw % R, pw % RV
+    auto cslot = [&](int p) {                                             // word base of CN position p
+        int sl = cb + (p - pw);
+        sl -= sl >= R ? R : 0;
+        sl += sl < 0 ? R : 0;
+        return sl * Cw;
+    };
+    auto sslot = [&](int qq) {                                            // word base of VN position qq
+        int sl = vb + (qq - pw);
+        sl -= sl >= RV ? RV : 0;
+        sl += sl < 0 ? RV : 0;
+        return sl * wpp;
+    };
     auto nib = [&](int p, int l) { return (cnt[cslot(p) + (l >> 3)] >> ((l & 7) * 4)) & 15u; };
 
     for (int i = tid; i < R * Cw; i += kBlock) cnt[i] = 0;
@@ -188,33 +201,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
                     const uint32_t o = (atomicSub(&cnt[cslot(jq + i) + (ll[i] >> 3)], 1u << sh) >> sh) & 15u;
                     if (o == 2u && jq + i < phi) {                        // 2 -> 1 inside the window: fires next iteration
                         const int idx = atomicAdd(push, 1);
-                        if (idx < qcap) qn[idx] = (uint32_t)((jq + i) * C) + ll[i]; else *ovf = 1;
+                        if (idx < qcap) qn[idx] = ((uint32_t)(jq + i) << 16) | ll[i]; else *ovf = 1;   // [CN position | CN]
                     }
                 }
             };
             if (scan) {
                 // snapshot {c in the window : count == 1} first: this round's releases must not promote CNs into it
-                const int nwords = (phi - posW) * Cw;
-                for (int i = tid; i < nwords; i += kBlock) {
-                    const int p = posW + i / Cw, w = i % Cw;
-                    const uint32_t y = cnt[cslot(p) + w] ^ 0x11111111u;
-                    fbits[i] = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
-                }
-                __syncthreads();
-                for (int i = tid; i < nwords; i += kBlock) {
-                    uint32_t z = fbits[i];
-                    const int p = posW + i / Cw, w = i % Cw;
-                    while (z) {
-                        const int k = (__ffs((int)z) - 1) >> 2;
-                        z &= z - 1;
-                        if (w * 8 + k < C) release(p, w * 8 + k);
+                for (int p = posW; p < phi; p++)
+                    for (int w = tid; w < Cw; w += kBlock) {
+                        const uint32_t y = cnt[cslot(p) + w] ^ 0x11111111u;
+                        fbits[(p - posW) * Cw + w] = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
                     }
-                }
+                __syncthreads();
+                for (int p = posW; p < phi; p++)
+                    for (int w = tid; w < Cw; w += kBlock) {
+                        uint32_t z = fbits[(p - posW) * Cw + w];
+                        while (z) {
+                            const int k = (__ffs((int)z) - 1) >> 2;
+                            z &= z - 1;
+                            if (w * 8 + k < C) release(p, w * 8 + k);
+                        }
+                    }
             } else {
-                for (int k = tid; k < ncur; k += kBlock) {
-                    const int c = (int)qc[k], p = c / C;
-                    release(p, c - p * C);
-                }
+                for (int k = tid; k < ncur; k += kBlock) release((int)(qc[k] >> 16), (int)(qc[k] & 0xFFFFu));
             }
             removed = wave_sum(removed);
             if (lane == 0 && removed) atomicAdd(rem, removed);
@@ -234,6 +243,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
         if (posW + W < L) enter(posW + W);                                // the next window's new position
         else __syncthreads();
         if (posW - (DV - 1) >= 0) expurgate(posW - (DV - 1));             // CN positions up to posW are final now
+        pw = posW + 1;
+        cb = cb + 1 == R ? 0 : cb + 1;
+        vb = vb + 1 == RV ? 0 : vb + 1;
     }
     __syncthreads();
     for (int qe = max(L - (DV - 1), 0); qe < L; qe++) expurgate(qe);       // the last positions: everything is final
