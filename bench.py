@@ -127,15 +127,20 @@ def cpu_baseline_c3(eps, per_core=4):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def measured_traffic(kernel, batch, workload):
-    """HBM bytes per launch of `kernel` from the committed PMC summary, if it was taken on this workload and batch."""
+def measured_traffic(kernel, batch, config):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json, written by
+    tools/summarize_prof.py from separate rocprofv3 --pmc passes), if it was taken on this config and batch."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("workload") == workload and t.get("batch") == batch and kernel in t.get("kernels", {}):
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(config, {})
+        if t.get("batch") == batch and kernel in t.get("kernels", {}):
             return t["kernels"][kernel]
     except Exception:
         pass
     return None
+
+
+def _traffic_fields(tr):
+    return {"traffic": tr["hbm_bytes"] if tr else None, "traffic_raw": tr["hbm_bytes_raw"] if tr else None}
 
 
 def main():
@@ -164,12 +169,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # One rank per GPU over RCCL.  Rehearsal on a box with fewer GPUs than ranks (tests/test_gpu_bench_ranks.py: two ranks
+    # on the one GPU of a test box): SCLDPC_BENCH_BACKEND=gloo, ranks wrap around the devices; never used for a reported line.
+    backend = os.environ.get("SCLDPC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > 1 and local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); RCCL needs one device per rank")
+    local_dev = local % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
+    if backend != "nccl" or world > ndev:
+        global REHEARSAL
+        REHEARSAL = f"backend={backend}, {world} ranks on {ndev} device(s)"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -191,6 +209,15 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+REHEARSAL = None
+
+
+def emit(out):
+    if REHEARSAL:
+        out["config"]["rehearsal"] = REHEARSAL      # not a reportable line: ranks shared devices / no RCCL
+    print(json.dumps(out), flush=True)
 
 
 def _events(n, k):
@@ -279,7 +306,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     value = total_trials / dt
     dec_name = "full_bp_kernel" if a.flooding else "full_bp_small_kernel" if gen2 else "full_bp_fixpoint_kernel"
     samp_name = "sample_philox_v2_kernel" if gen2 else "sample_philox_kernel"
-    tr_dec, tr_samp = measured_traffic(dec_name, B, workload), measured_traffic(samp_name, B, workload)
+    tr_dec, tr_samp = measured_traffic(dec_name, B, "C2"), measured_traffic(samp_name, B, "C2")
     ach_dec = share * B / (ms_bp * 1e-3) / 1e9
     ach_samp = share * B / (ms_sample * 1e-3) / 1e9
     step_ach = b_alg * value / world / 1e9
@@ -333,7 +360,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c2(EPS)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -395,15 +422,15 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
                       "trials_per_gpu_per_step": B, "step": "device sample -> peel_pick (r1 rows) -> r1_moments",
                       "parallelism": f"trial-sharded x{world}"},
            "roofline": {"bound": "hbm", "kernel": "peel_pick_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_trial": b_alg,
-                        "moments_bytes_per_batch": 24 * (steps_pd + 1), "ms_per_launch": ms_p,
+                        "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("peel_pick_kernel", B, "C3")),
+                        "alg_bytes_per_trial": b_alg, "moments_bytes_per_batch": 24 * (steps_pd + 1), "ms_per_launch": ms_p,
                         "note": "a chain of 290 000 dependent picks per trial: latency-bound (SURVEY.md §8d says so); the "
                                 "fraction of the HBM roofline is reported, not expected to be high"},
            "kernels_ms": {"sample_philox_big": ms_s, "peel_pick": ms_p},
            "results": {"mean_r1_at_step_0": float(m[1][0]) / max(1.0, float(m[0][0])), "trials_in_moments": int(m[0][0])}}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c3(EPS)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -473,7 +500,8 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
                                "device sample -> CN->socket table -> decodeBP_SW (window state in LDS) -> plr_computation"),
                       "parallelism": f"trial-sharded x{world} (the eps grid shards by point in bp_decoding.py)"},
            "roofline": {"bound": "hbm", "kernel": "sw_ring_kernel" if gen2 else "sw_ring_kernel (+ cn_sockets_kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_trial": share, "ms_per_launch": ms_w,
+                        "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("sw_ring_kernel", B, "C4")),
+                        "alg_bytes_per_trial": share, "ms_per_launch": ms_w,
                         "literal_flooding": {"bytes": "8*E_w*sum I, E_w = W*N*dv", "sum_iterations": r["iterations"],
                                              "equivalent_GBs": lit, "x_peak": lit / HBM_PEAK_GBS},
                         "step": {"achieved": b_alg * value / world / 1e9, "frac": b_alg * value / world / 1e9 / HBM_PEAK_GBS}},
@@ -482,7 +510,7 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
                        "BER": r["users_err"] / p.n / r["frames"], "mean_window_iterations": r["iterations"] / r["frames"]}}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c4(EPS, W, IT)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -525,13 +553,14 @@ def run_c5(a, E, dev, rank, world, dist, fence, finish):
                       "streams_per_gpu": NS, "positions_per_stream_per_step": CHUNK,
                       "step": "generate_stream_pos + decodeBP_SW_circular per position", "parallelism": f"stream-sharded x{world}"},
            "roofline": {"bound": "hbm", "kernel": "stream_bp_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_position": b_alg, "ms_per_launch": ms,
+                        "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("stream_bp_kernel", NS, "C5")),
+                        "alg_bytes_per_position": b_alg, "ms_per_launch": ms,
                         "note": "per-stream state is L2-resident between positions; the window rounds are latency-bound"},
            "results": {"BLER": float(c[1]) / max(1.0, float(c[5])), "BLER_exp": float(c[3]) / max(1.0, float(c[7])),
                        "BER": float(c[0]) / max(1.0, float(c[4])), "blocks": int(c[5])}}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c5(EPS, W, DOPED)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":

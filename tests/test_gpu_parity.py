@@ -382,14 +382,13 @@ def test_fixpoint_kernel_equals_flooding_kernel(E, L, N, eps, is_term):
         assert (out["erased"].cpu().numpy() == ref["erased"].cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("name", golden_names(variants=("bpf",)))
+@pytest.mark.parametrize("name", golden_names(variants=("bpf",), uncapped=True))
 def test_fixpoint_kernel_matches_reference_golden(E, name):
     """The real reference's unlimited-iteration outputs (fixtures with max_it = 0 only)."""
     import torch
     g = load_golden(name)
     m = g.meta
-    if g.max_it:
-        pytest.skip("fixture with an iteration cap")
+    assert not g.max_it
     p, T, (d_adj, d_ch) = _golden_inputs(E, g)
     out = E.full_bp_fixpoint(p, d_adj, d_ch, is_term=bool(m["is_term"]), want_erased=True)
     torch.cuda.synchronize()

@@ -69,7 +69,8 @@ def test_small_decoder_equals_flooding_and_fixpoint_kernels(E, L, N, eps, is_ter
     assert torch.equal(ref["erased"], sm["erased"])
 
 
-@pytest.mark.parametrize("name", golden_names(prefixes=("c2_bpf", "mid_bpf", "tiny_bpf", "ss2_bpf", "mid_bpt", "tiny_bpt")))
+@pytest.mark.parametrize("name", golden_names(prefixes=("c2_bpf", "mid_bpf", "tiny_bpf", "ss2_bpf", "mid_bpt", "tiny_bpt"),
+                                               uncapped=True))
 def test_small_decoder_on_reference_fixtures(E, name):
     """The reference's own graphs and channels (glibc replay on the fixture's seeds), CN -> VN table built on the host:
     the unlimited-iteration fixtures' counters (incl. the size-2 stopping-set expurgation of the Def_M = 3 ensembles) and
@@ -77,8 +78,7 @@ def test_small_decoder_on_reference_fixtures(E, name):
     import torch
     g = load_golden(name)
     m = g.meta
-    if g.max_it:
-        pytest.skip("capped fixture: the fixpoint kernels take unlimited iterations only")
+    assert not g.max_it
     p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
     T = min(g.T, 16 if p.n > 10000 else 64)
     adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])

@@ -19,7 +19,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("full_bp_small_kernel", "sample_philox_v2_kernel", "full_bp_fixpoint_kernel", "full_bp_kernel", "sample_philox_kernel",
+WORKLOADS = {"C2": "(4,8) SC-LDPC L=50 N=1000 eps=0.48 full BP unlimited iterations",
+             "C3": "(4,8) SC-LDPC L=50 N=10000 eps=0.48 random-pick peeling, 290000 steps per trial",
+             "C4": "(4,8) SC-LDPC L=100 N=2000 eps=0.47 decodeBP_SW W=10 I_max=20",
+             "C5": "doped (4,8) streaming ensemble N=5000 L=50 W=20 (batch = streams per launch, 16 positions each)"}
+KERNELS = ("sw_ring_kernel", "cn_sockets_kernel", "r1_moments_kernel", "full_bp_small_kernel", "sample_philox_v2_kernel", "full_bp_fixpoint_kernel", "full_bp_kernel", "sample_philox_kernel",
            "sample_philox_big_kernel", "sw_bp_kernel", "accumulate_run_kernel", "peel_pick_kernel", "peel_sweep_kernel",
            "stream_bp_kernel")
 
@@ -34,6 +38,9 @@ def short(name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32768      # bench.py's default batch
+    config = sys.argv[3] if len(sys.argv) > 3 else "C2"           # tools/profile.sh TAG [CONFIG]
+    if config != "C2":
+        tag = f"{tag}_{config}"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -79,12 +86,13 @@ def main():
                           "rdreq": rdreq}
         out["kernels"][k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-    json.dump({"workload": "(4,8) SC-LDPC L=50 N=1000 eps=0.48 full BP unlimited iterations", "batch": batch,
-               "kernels": traffic,
-               "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum, separate "
-                         "passes of `python bench.py --steps 2 --warmup 1`; read bytes = 128 B x requests = 2 x FETCH_SIZE, "
-                         f"calibrated by tools/calib -> profiles/{tag}_calibration.txt)"},
-              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    tpath = os.path.join(dst, "traffic.json")
+    allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    allt[config] = {"workload": WORKLOADS[config], "batch": batch, "kernels": traffic,
+                    "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum, separate "
+                              f"passes of `python bench.py --config {config} --steps 2 --warmup 1`; read bytes = 128 B x requests "
+                              "= 2 x FETCH_SIZE, calibrated by tools/calib -> profiles/r02_calibration.txt)"}
+    json.dump(allt, open(tpath, "w"), indent=1)
     print(json.dumps(out, indent=1))
     # ---- SQ counters: instruction mix and pipe occupancy (which pipe bounds which kernel)
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
