@@ -153,8 +153,8 @@ def main():
     ap.add_argument("--eps", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flooding", action="store_true",
-                    help="C2: decode with the level-synchronous kernel (one barrier round per flooding iteration, reports "
-                         "the iteration count and the literal-flooding figure) instead of the fixpoint kernels")
+                    help="C2: decode one flooding iteration per barrier round (scldpc_full_bp_device_cn16; with --gen1 the "
+                         "16-bit-CN-word kernel): reports the iteration count and the literal-flooding figure")
     ap.add_argument("--overlap", action="store_true",
                     help="(default) two streams, two buffers: the sampler of step k+1 fills the tail of the decoder of step k")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
@@ -233,7 +233,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch or 32768
     workload = f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} full BP unlimited iterations"
-    gen2 = not (a.gen1 or a.flooding or a.adj32)
+    gen2 = not (a.gen1 or a.adj32)
     if gen2 and not E.cn16_supported(p):
         raise SystemExit("bench.py: the second-generation kernels do not take this ensemble")
     # Two streams by default: two (tables, channel, counters) buffers, the sampler of step k+1 beside the decoder of step k.
@@ -270,7 +270,9 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
             s_dec.wait_event(sampled[b])
             if e:
                 e[2].record(s_dec)
-            if a.flooding:
+            if a.flooding and gen2:
+                E.full_bp_cn16(p, d_adj[b], d_cn[b], d_ch[b], counters=d_cnt[b])
+            elif a.flooding:
                 E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
             elif gen2:
                 E.full_bp_fixpoint_cn16(p, d_adj[b], d_cn[b], d_ch[b], counters=d_cnt[b])
@@ -304,9 +306,11 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     b_alg = 16 * E_edges + p.n // 8
     share = 8 * E_edges + p.n // 8                      # each kernel's half: one direction of both tables + the channel bits
     value = total_trials / dt
-    dec_name = "full_bp_kernel" if a.flooding else "full_bp_small_kernel" if gen2 else "full_bp_fixpoint_kernel"
+    dec_name = "full_bp_small_kernel" if gen2 else "full_bp_kernel" if a.flooding else "full_bp_fixpoint_kernel"
     samp_name = "sample_philox_v2_kernel" if gen2 else "sample_philox_kernel"
     tr_dec, tr_samp = measured_traffic(dec_name, B, "C2"), measured_traffic(samp_name, B, "C2")
+    if a.flooding:
+        tr_dec = None                                   # the PMC passes under profiles/ are of the fixpoint variant
     ach_dec = share * B / (ms_bp * 1e-3) / 1e9
     ach_samp = share * B / (ms_sample * 1e-3) / 1e9
     step_ach = b_alg * value / world / 1e9
@@ -343,7 +347,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": workload, "trials_per_gpu_per_step": B,
                    "step": "device sample (code+channel) -> decodeBP -> plr_computation",
-                   "decoder": ("flooding, one barrier round per iteration" if a.flooding else
+                   "decoder": ("flooding, one barrier round per iteration (iteration counts and caps as the reference's)" if a.flooding else
                                "fixpoint of unlimited flooding by chain-following peeling (every output of decodeBP "
                                "except the iteration count; equality with the flooding kernel on every trial is a test)"),
                    "kernels": "sampler_v2 + full_bp_small (4-bit CN counts, CN->VN table)" if gen2 else "first generation",

@@ -34,7 +34,7 @@ EXPORTS = (
     "scldpc_full_bp_fixpoint_device", "scldpc_full_bp_fixpoint_device_adj16",
     "scldpc_sample_philox_cn16_supported", "scldpc_sample_philox_device_cn16",
     "scldpc_sample_philox_sock16_supported", "scldpc_sample_philox_device_sock16",
-    "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16",
+    "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16", "scldpc_full_bp_device_cn16",
     "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
     "scldpc_sw_bp_ring_supported", "scldpc_cn_sockets_device", "scldpc_sw_bp_ring_device",
 )
@@ -79,6 +79,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ScldpcError(f"{LIB_PATH} is missing — build it with `make -C fl_scaling_sc_ldpc_amd/csrc` "
                           "(hipcc, gfx950).  There is no CPU fallback.")
+    # PyTorch's copy of the HIP runtime first: loaded after this library it would be a second runtime in the process, and
+    # whichever of the two touches the GPU second finds no device
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     vp, i32, i64, u32, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
@@ -104,6 +107,7 @@ def lib():
     L.scldpc_sample_philox_sock16_supported.argtypes = [pp]
     L.scldpc_sample_philox_device_sock16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.scldpc_full_bp_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, u64, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes

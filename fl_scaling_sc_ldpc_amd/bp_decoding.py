@@ -139,15 +139,18 @@ class Simulator:
         self.d_adj = torch.empty((batch, p.n, p.dv), dtype=adj_dtype, device=self.device)
         self.d_ch = torch.empty((batch, p.nw), dtype=torch.int32, device=self.device)
         self.d_cnt = torch.empty((batch, NCOUNTERS), dtype=torch.int32, device=self.device)
-        # unlimited full BP without iteration statistics on the BASELINE ensemble family: the second-generation pair
-        # (sampler_v2 + the 4-bits-per-CN decoder) needs the CN -> VN table next to the VN -> CN one
-        self.gen2 = (self.rng == "philox" and self.decoder == "full" and self.schedule == "fixpoint" and self.rows_cap == 0
-                     and (self.max_it <= 0 or self.max_it >= 1000000) and E.cn16_supported(p))
+        # full BP on the BASELINE ensemble family: the second-generation pair (sampler_v2 + the 4-bits-per-CN decoder) needs
+        # the CN -> VN table next to the VN -> CN one.  gen2: unlimited, no iteration statistics (fixpoint); lvl2: the same
+        # decoder walked one flooding iteration per round — iteration caps (the published ..._500it_... tables) and counts
+        cn16 = self.rng == "philox" and self.decoder == "full" and self.rows_cap == 0 and E.cn16_supported(p)
+        self.gen2 = cn16 and self.schedule == "fixpoint" and (self.max_it <= 0 or self.max_it >= 1000000)
+        self.lvl2 = cn16 and not self.gen2
         # square-window decoding with the window's state in LDS reads a CN -> socket table: sampled with the code where the
         # second-generation sampler takes the ensemble (else E.sw_bp builds it in a pass of its own)
         self.ring2 = (self.rng == "philox" and self.decoder == "sw" and adj_dtype == torch.int16
                       and E.sock16_supported(p) and E.sw_ring_supported(p, self.W))
-        self.d_cn = torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device) if (self.gen2 or self.ring2) else None
+        self.d_cn = (torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device)
+                     if (self.gen2 or self.lvl2 or self.ring2) else None)
 
     def _accumulate(self, allcnt, run, stop_frame_err):
         return E.accumulate_run(allcnt, run, stop_frame_err)
@@ -163,13 +166,15 @@ class Simulator:
                            d_cn_sock=self.d_cn[:nb] if self.ring2 else None)
         if self.gen2 and not want_rows:
             return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt)
+        if self.lvl2 and not want_rows:
+            return E.full_bp_cn16(self.p, adj, self.d_cn[:nb], ch, max_it=self.max_it, is_term=self.is_term, counters=cnt)
         if self.schedule == "fixpoint" and not want_rows and (self.max_it <= 0 or self.max_it >= 1000000):
             return E.full_bp_fixpoint(self.p, adj, ch, is_term=self.is_term, counters=cnt)    # no iteration counts
         return E.full_bp(self.p, adj, ch, max_it=self.max_it, is_term=self.is_term,
                          rows_cap=self.rows_cap if want_rows else 0, counters=cnt)
 
     def fill_batch(self, sim, eps, frame0, nb):
-        if self.rng == "philox" and self.gen2:
+        if self.rng == "philox" and (self.gen2 or self.lvl2):
             E.sample_philox_cn16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
                                  out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox" and self.ring2:

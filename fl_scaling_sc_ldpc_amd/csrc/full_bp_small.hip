@@ -14,7 +14,15 @@
 // neighbour with its U bit still set — the unclaimed one — and if that neighbour is being released elsewhere at that
 // moment the bit is already clear and the entry is dropped (that release will take the count to zero).
 //
-// Outputs: the counters of scldpc_full_bp_fixpoint_device (everything decodeBP reports except the iteration count).
+// LEVEL = true is the same machine walked one flooding iteration per barrier round (scldpc_full_bp_device_cn16): a round
+// releases exactly the CNs whose count was one when it began, so round t is the reference's iteration t (SURVEY.md §7.4 A;
+// full_bp.hip does the same on 16-bit CN words with two trials per CU) — iteration count, the cap MaxNumIt (BPF:1065), the
+// stop tests (BPF:1044-1045) and deg_1_iter's invariant (BPF:1035-1039) included.  Rounds whose frontier does not fit the
+// queue (the first one or two) take it from a snapshot bitmap, one queue-full at a time; that bitmap costs a seventh trial
+// per CU (six fit).
+//
+// Outputs: the counters of scldpc_full_bp_fixpoint_device (everything decodeBP reports except the iteration count), or
+// with LEVEL all of scldpc_full_bp_device's counters.
 // The size-2 stopping-set expurgation only looks at what the reference reports: the FIRST position with a positive
 // expurgated count (is_first_printed, BPF:1074, 1126-1132), so only that position's erased VNs are examined.
 #include "common.h"
@@ -25,12 +33,15 @@ namespace {
 using namespace scldpc_dev;
 
 enum { SC_NE = 0, SC_REM, SC_N0, SC_N1, SC_OVF, SC_Q, SC_N = 8 };
+// LEVEL: per-iteration counters rotated three ways, so that one barrier per iteration is enough (as in full_bp.hip)
+enum { LV_VALID = 2, LV_PUSH = 6, LV_DROP = 9, LV_REM = 12, LV_OVF = 15, LV_N = 18 };
 
 struct SmArgs {
     int L, V, C, n, nk, cn_lim, nw, ncw;            // ncw = words of 8 count nibbles
     uint32_t magic_v, magic_c;
     int kswitch;                                    // frontier width below which the waves go private
-    int off_U, off_q0, off_q1, off_pos, off_scal, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
+    int max_it;                                     // LEVEL: MaxNumIt, <= 0 = unlimited
+    int off_U, off_q0, off_q1, off_pos, off_scal, off_fb, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
     const uint16_t *vn_adj16;                       // [T][n][4]   CN index local to its position
     const uint16_t *cn_adj16;                       // [T][nk][8]  VNs of every CN (0xFFFF: none)
     const uint32_t *chan;
@@ -39,7 +50,7 @@ struct SmArgs {
 };
 
 // Seven 4-wave workgroups per CU are 7 waves per SIMD: at most 96 SGPRs and 72 VGPRs per wave (MI355X_MICROARCH.md).
-template <int BLOCK>
+template <int BLOCK, bool LEVEL>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
 {
     constexpr int kWaves = BLOCK / 64;
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
         U[w] = x;
         ne_local += __popc(x);
     }
-    if (tid < SC_N) scal[tid] = 0;
+    if (tid < LV_N) scal[tid] = 0;
     for (int i = tid; i < 2 * L; i += BLOCK) pos_cnt[i] = 0;
     __syncthreads();
     ne_local = wave_sum(ne_local);
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
 
     // ---- one release step: CN c is believed to have exactly one erased neighbour -----------------------------------
     // out[i] = 1 + the CN on edge i of the released VN if this release left it with one erased neighbour, else 0
-    int removed = 0;
+    int removed = 0, drops = 0;                                          // drops (LEVEL): counts taken from one to zero
     auto step = [&](int c, uint32_t (&out)[4]) {
         out[0] = out[1] = out[2] = out[3] = 0;
         const uint4 s4 = crow[c];
@@ -129,113 +140,218 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
 #pragma unroll
         for (int i = 0; i < 4; i++) o[i] = atomicSub(&cnt[cc[i] >> 3], 1u << ((cc[i] & 7) * 4));
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (((o[i] >> ((cc[i] & 7) * 4)) & 15u) == 2u && cc[i] < cn_lim) out[i] = (uint32_t)cc[i] + 1u;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t old = (o[i] >> ((cc[i] & 7) * 4)) & 15u;
+            if (old == 2u && cc[i] < cn_lim) out[i] = (uint32_t)cc[i] + 1u;
+            if constexpr (LEVEL) drops += (old == 1u && cc[i] < cn_lim);
+        }
+    };
+    // the CNs of a count word whose count is one, as a mask of the nibbles' top bits, CNs >= cn_lim dropped
+    auto ones_of = [&](int w) {
+        const uint32_t y = cnt[w] ^ 0x11111111u;                         // nibble == 1  <=>  zero nibble of y
+        uint32_t z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+        if (w * 8 + 8 > cn_lim) {                                        // the word that holds cn_lim
+            const int keep = cn_lim - w * 8;
+            z = keep <= 0 ? 0u : (z & ((1u << (4 * keep)) - 1u));
+        }
+        return z;
+    };
+    // a wave appends its lanes' out[] entries to queue qn behind *push (one prefix scan + one LDS atomic per wave)
+    auto append = [&](const uint32_t (&out)[4], int *push, uint16_t *qn, bool &overflow) {
+        const int mine = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+        const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (tot) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(push, tot);
+            int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (out[i]) { if (idx < qcap) qn[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
+        }
     };
 
-    // ---- peel: barrier rounds over a shared queue while the frontier is wide (a scan opens the run and repairs an
-    //      overflow), then every wave runs the CNs its own releases create from a private queue, level after level ----
-    const int kSwitch = a.kswitch;
-    const int wcap = (qcap / kWaves) & ~1, half_cap = wcap / 2;
-    int rounds = 0, ncur = 0;
-    bool scan = true;
-    for (;;) {
-        uint16_t *qc = q[rounds & 1], *qn = q[(rounds + 1) & 1];
-        if (scan) {
-            // every CN < cn_lim whose count is one right now, compacted into qc
-            for (int w0 = wave * 64; w0 < a.ncw; w0 += BLOCK) {
-                const int w = w0 + lane;
-                uint32_t z = 0;
-                if (w < a.ncw) {
-                    const uint32_t y = cnt[w] ^ 0x11111111u;             // nibble == 1  <=>  zero nibble of y
-                    z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
-                    if (w * 8 + 8 > cn_lim) {                            // the word that holds cn_lim: drop the CNs beyond it
-                        const int keep = cn_lim - w * 8;
-                        z = keep <= 0 ? 0u : (z & ((1u << (4 * keep)) - 1u));
+    int rounds = 0, ne = 0, status = 0;
+    if constexpr (LEVEL) {
+        // ---- one flooding iteration per barrier round (decodeBP's do-while, BPF:927-1065) ------------------------------
+        uint8_t *fb = reinterpret_cast<uint8_t *>(lds + a.off_fb);       // snapshot of a scan round: one byte per count word
+        int prec = n, iter = 0, ncur = 0, nfront = 0;
+        bool scan = true;                                                // iteration 0 has no queue yet
+        ne = nch;
+        for (;;) {
+            const int g = iter % 3, gn = (iter + 1) % 3;
+            uint16_t *qc = q[iter & 1], *qn = q[(iter + 1) & 1];
+            if (tid == 0) { scal[LV_PUSH + gn] = 0; scal[LV_DROP + gn] = 0; scal[LV_REM + gn] = 0; scal[LV_OVF + gn] = 0; }
+            int *push = &scal[LV_PUSH + g];                              // counts every 2 -> 1, queued or not
+            bool overflow = false;
+            removed = 0; drops = 0;
+            auto run_queue = [&](int nq) {
+                for (int k0 = wave * 64; k0 < nq; k0 += BLOCK) {
+                    uint32_t out[4] = {0, 0, 0, 0};
+                    if (k0 + lane < nq) step((int)qc[k0 + lane], out);
+                    append(out, push, qn, overflow);
+                }
+            };
+            if (scan) {
+                // snapshot {c < cn_lim : count == 1} BEFORE any release of this round (releases must not promote CNs into it),
+                // then one queue-full of it at a time
+                int valid = 0;
+                for (int w = tid; w < a.ncw; w += BLOCK) {
+                    uint32_t y = ones_of(w) >> 3;                        // bit 4k: CN 8w+k
+                    y = (y | (y >> 3)) & 0x03030303u;
+                    y = (y | (y >> 6)) & 0x000F000Fu;
+                    y = (y | (y >> 12)) & 0xFFu;                         // bit k: CN 8w+k
+                    fb[w] = (uint8_t)y;
+                    valid += __popc(y);
+                }
+                if (iter == 0) {
+                    valid = wave_sum(valid);
+                    if (lane == 0 && valid) atomicAdd(&scal[LV_VALID], valid);
+                }
+                if (tid == 0) scal[SC_Q] = 0;
+                __syncthreads();
+                if (iter == 0) nfront = scal[LV_VALID];
+                for (;;) {
+                    for (int w0 = wave * 64; w0 < a.ncw; w0 += BLOCK) {  // thread t owns bytes t, t + BLOCK, …
+                        const int w = w0 + lane;
+                        uint32_t y = w < a.ncw ? (uint32_t)fb[w] : 0u;
+                        const int mine = __popc(y);
+                        const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                        const int tot = __builtin_amdgcn_readlane(incl, 63);
+                        if (tot == 0) continue;
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&scal[SC_Q], tot);
+                        int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+                        uint32_t left = 0;
+                        while (y) {
+                            const int k = __ffs((int)y) - 1;
+                            y &= y - 1;
+                            if (idx < qcap) qc[idx] = (uint16_t)(w * 8 + k); else left |= 1u << k;
+                            idx++;
+                        }
+                        if (mine) fb[w] = (uint8_t)left;
                     }
+                    __syncthreads();
+                    const int found = scal[SC_Q];
+                    __syncthreads();
+                    if (tid == 0) scal[SC_Q] = 0;
+                    run_queue(min(found, qcap));
+                    if (found <= qcap) break;
+                    __syncthreads();                                     // this queue-full is done before qc is refilled
                 }
-                const int mine = __popc(z);
-                const int incl = (int)wave_inclusive_scan((uint32_t)mine);
-                const int tot = __builtin_amdgcn_readlane(incl, 63);
-                if (tot == 0) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&scal[SC_Q], tot);
-                base = __builtin_amdgcn_readfirstlane(base);
-                int idx = base + incl - mine;
-                while (z) {
-                    const int k = (__ffs((int)z) - 1) >> 2;
-                    z &= z - 1;
-                    if (idx < qcap) qc[idx] = (uint16_t)(w * 8 + k);
-                    idx++;
-                }
+            } else {
+                run_queue(ncur);
             }
-            __syncthreads();
-            ncur = scal[SC_Q];
-            if (ncur > qcap) { ncur = qcap; if (tid == 0) scal[SC_OVF] = 1; }      // the rest: next scan
-            __syncthreads();
+            removed = wave_sum(removed);
+            drops = wave_sum(drops);
+            if (lane == 0) {
+                if (removed) atomicAdd(&scal[LV_REM + g], removed);
+                if (drops) atomicAdd(&scal[LV_DROP + g], drops);
+            }
+            if (overflow) scal[LV_OVF + g] = 1;
+            __syncthreads();                                             // end of flooding iteration `iter`
+            // ---- bookkeeping, identical in every thread (full_bp.hip)
+            const int deg1 = nfront;                                     // deg_1_iter, BPF:969-978
+            ne -= scal[LV_REM + g];
+            const int recovered = prec - ne;
+            rounds++;
+            if (deg1 < recovered && iter > 0) { status = -1; break; }    // BPF:1035-1039
+            if (ne == 0 || ne == prec) break;                            // BPF:1044-1045
+            prec = ne;
+            // next frontier: queued 2 -> 1 CNs minus those that went on to 0 within this round
+            nfront = scal[LV_PUSH + g] - (scal[LV_DROP + g] - nfront);
+            scan = scal[LV_OVF + g] != 0;
+            ncur = scan ? 0 : scal[LV_PUSH + g];
+            iter++;
+            if (a.max_it > 0 && iter >= a.max_it) break;                 // BPF:1065
         }
-        if (tid == 0) { scal[SC_Q] = 0; scal[SC_N0 + ((rounds + 1) & 1)] = 0; }
-        int *push = &scal[SC_N0 + (rounds & 1)];
-        bool overflow = false;
-        if (ncur > kSwitch || half_cap < 64) {
-            for (int k0 = wave * 64; k0 < ncur; k0 += BLOCK) {
-                uint32_t out[4] = {0, 0, 0, 0};
-                if (k0 + lane < ncur) step((int)qc[k0 + lane], out);
-                {   // append: one prefix scan + one LDS atomic per wave for all four edges
-                    const int mine = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+        __syncthreads();
+        STAMP(1);
+    } else {
+        // ---- peel: barrier rounds over a shared queue while the frontier is wide (a scan opens the run and repairs an
+        //      overflow), then every wave runs the CNs its own releases create from a private queue, level after level ----
+        const int kSwitch = a.kswitch;
+        const int wcap = (qcap / kWaves) & ~1, half_cap = wcap / 2;
+        int ncur = 0;
+        bool scan = true;
+        for (;;) {
+            uint16_t *qc = q[rounds & 1], *qn = q[(rounds + 1) & 1];
+            if (scan) {
+                // every CN < cn_lim whose count is one right now, compacted into qc
+                for (int w0 = wave * 64; w0 < a.ncw; w0 += BLOCK) {
+                    const int w = w0 + lane;
+                    uint32_t z = w < a.ncw ? ones_of(w) : 0u;
+                    const int mine = __popc(z);
                     const int incl = (int)wave_inclusive_scan((uint32_t)mine);
                     const int tot = __builtin_amdgcn_readlane(incl, 63);
-                    if (tot) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(push, tot);
-                        int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (out[i]) { if (idx < qcap) qn[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
+                    if (tot == 0) continue;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&scal[SC_Q], tot);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    int idx = base + incl - mine;
+                    while (z) {
+                        const int k = (__ffs((int)z) - 1) >> 2;
+                        z &= z - 1;
+                        if (idx < qcap) qc[idx] = (uint16_t)(w * 8 + k);
+                        idx++;
                     }
                 }
+                __syncthreads();
+                ncur = scal[SC_Q];
+                if (ncur > qcap) { ncur = qcap; if (tid == 0) scal[SC_OVF] = 1; }      // the rest: next scan
+                __syncthreads();
             }
-        } else {
-            // private phase: wave w takes entries w, w + kWaves, … into its own part of qn and runs to exhaustion
-            uint16_t *mine = qn + wave * wcap;
-            int cntw = (ncur - wave + kWaves - 1) / kWaves, cur = 0;
-            if (cntw < 0) cntw = 0;
-            if (lane < cntw) mine[lane] = qc[wave + lane * kWaves];
-            while (cntw > 0) {
-                uint16_t *src = mine + cur * half_cap, *dst = mine + (cur ^ 1) * half_cap;
-                int ncnt = 0;
-                for (int b0 = 0; b0 < cntw; b0 += 64) {
+            if (tid == 0) { scal[SC_Q] = 0; scal[SC_N0 + ((rounds + 1) & 1)] = 0; }
+            int *push = &scal[SC_N0 + (rounds & 1)];
+            bool overflow = false;
+            if (ncur > kSwitch || half_cap < 64) {
+                for (int k0 = wave * 64; k0 < ncur; k0 += BLOCK) {
                     uint32_t out[4] = {0, 0, 0, 0};
-                    if (b0 + lane < cntw) step((int)src[b0 + lane], out);
-                    {   // append: wave-synchronous, no atomics
-                        const int mine_n = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
-                        const int incl = (int)wave_inclusive_scan((uint32_t)mine_n);
-                        int idx = ncnt + incl - mine_n;
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (out[i]) { if (idx < half_cap) dst[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
-                        ncnt += __builtin_amdgcn_readlane(incl, 63);
-                    }
+                    if (k0 + lane < ncur) step((int)qc[k0 + lane], out);
+                    append(out, push, qn, overflow);
                 }
-                cntw = min(ncnt, half_cap);
-                cur ^= 1;
+            } else {
+                // private phase: wave w takes entries w, w + kWaves, … into its own part of qn and runs to exhaustion
+                uint16_t *mine = qn + wave * wcap;
+                int cntw = (ncur - wave + kWaves - 1) / kWaves, cur = 0;
+                if (cntw < 0) cntw = 0;
+                if (lane < cntw) mine[lane] = qc[wave + lane * kWaves];
+                while (cntw > 0) {
+                    uint16_t *src = mine + cur * half_cap, *dst = mine + (cur ^ 1) * half_cap;
+                    int ncnt = 0;
+                    for (int b0 = 0; b0 < cntw; b0 += 64) {
+                        uint32_t out[4] = {0, 0, 0, 0};
+                        if (b0 + lane < cntw) step((int)src[b0 + lane], out);
+                        {   // append: wave-synchronous, no atomics
+                            const int mine_n = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+                            const int incl = (int)wave_inclusive_scan((uint32_t)mine_n);
+                            int idx = ncnt + incl - mine_n;
+    #pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (out[i]) { if (idx < half_cap) dst[idx] = (uint16_t)(out[i] - 1u); else overflow = true; idx++; }
+                            ncnt += __builtin_amdgcn_readlane(incl, 63);
+                        }
+                    }
+                    cntw = min(ncnt, half_cap);
+                    cur ^= 1;
+                }
             }
+            if (overflow) scal[SC_OVF] = 1;
+            __syncthreads();
+            rounds++;
+            const int pushed = *push;
+            scan = scal[SC_OVF] != 0;            // a full queue dropped CNs: find them by a scan
+            __syncthreads();
+            if (tid == 0) scal[SC_OVF] = 0;
+            ncur = scan ? 0 : min(pushed, qcap);
+            if (!scan && ncur == 0) break;
         }
-        if (overflow) scal[SC_OVF] = 1;
+        STAMP(1);                                                            // peeling
+        removed = wave_sum(removed);
+        if (lane == 0 && removed) atomicAdd(&scal[SC_REM], removed);
         __syncthreads();
-        rounds++;
-        const int pushed = *push;
-        scan = scal[SC_OVF] != 0;            // a full queue dropped CNs: find them by a scan
-        __syncthreads();
-        if (tid == 0) scal[SC_OVF] = 0;
-        ncur = scan ? 0 : min(pushed, qcap);
-        if (!scan && ncur == 0) break;
+        ne = nch - scal[SC_REM];
     }
-    STAMP(1);                                                            // peeling
-    removed = wave_sum(removed);
-    if (lane == 0 && removed) atomicAdd(&scal[SC_REM], removed);
-    __syncthreads();
-    const int ne = nch - scal[SC_REM];
 
     // ---- erased VNs per position (word w of U may straddle two positions) --------------------------------------------
     int be = 0, ee = 0, bee = 0;
@@ -302,13 +418,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
         o[SCLDPC_C_NUM_ERASURES_EXP] = ee;
         o[SCLDPC_C_NUM_BLOCKS_ERR_EXP] = bee;
         o[SCLDPC_C_NUM_ERASURES_P1] = 0;
-        o[SCLDPC_C_ITERATIONS] = rounds;                                 // barrier rounds, NOT flooding iterations
-        o[SCLDPC_C_STATUS] = 0;
+        o[SCLDPC_C_ITERATIONS] = rounds;                                 // LEVEL: flooding iterations; else barrier rounds
+        o[SCLDPC_C_STATUS] = status;
         o[SCLDPC_C_CHANNEL_ERASURES] = nch;
     }
 }
 
-int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_cu)
+int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_cu, bool level = false)
 {
     const int n = scldpc::n_of(p), nk = scldpc::nk_of(p);
     a->L = p->L; a->V = p->vns_pos; a->C = p->cns_pos; a->n = n; a->nk = nk;
@@ -319,7 +435,8 @@ int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_c
     take(a->ncw);
     a->off_U = take(a->nw);
     a->off_pos = take(2 * p->L);
-    a->off_scal = take(SC_N);
+    a->off_scal = take(LV_N);
+    a->off_fb = level ? take((a->ncw + 3) / 4) : 0;                      // snapshot bytes of the scan rounds
     const int budget = scldpc::kMaxLdsBytes / per_cu / 4 - 128;           // words per workgroup
     int qwords = ((budget - off) / 2) & ~3;                              // per queue; two uint16 entries per word
     if (qwords > 2048) qwords = 2048;
@@ -348,12 +465,12 @@ extern "C" int scldpc_full_bp_cn16_supported(const scldpc_code_params *p)
            scldpc::magic_of(p->cns_pos, scldpc::nk_of(p), &m);
 }
 
-extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntrials,
-                                                   const uint16_t *d_vn_adj16, const uint16_t *d_cn_adj16,
-                                                   const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
-                                                   uint32_t *d_erased_bits, void *stream)
+namespace {
+
+int launch_small(const char *who, bool level, const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                 const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                 int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
-    const char *who = "scldpc_full_bp_fixpoint_device_cn16";
     if (int rc = scldpc::check_params(p)) return rc;
     if (!scldpc_full_bp_cn16_supported(p))
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 65536 CNs and fewer than 65535 VNs per trial", who);
@@ -362,19 +479,40 @@ extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, 
     if (ntrials == 0) return SCLDPC_OK;
     SmArgs a{};
     int per_cu = kPerCu;                                               // workgroups per CU the LDS carve aims at
-    while (per_cu > 1 && make_args(p, is_term, &a, per_cu) != 0) per_cu--;
-    if (make_args(p, is_term, &a, per_cu) != 0)
+    while (per_cu > 1 && make_args(p, is_term, &a, per_cu, level) != 0) per_cu--;
+    if (make_args(p, is_term, &a, per_cu, level) != 0)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the CN counts and VN bits do not fit the LDS", who);
     scldpc::magic_of(p->vns_pos, a.n + 32, &a.magic_v);
     scldpc::magic_of(p->cns_pos, a.nk, &a.magic_c);
     a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
     a.counters = d_counters; a.erased_out = d_erased_bits;
     a.kswitch = kSwitchWidth;
-    void (*kern)(const SmArgs) = full_bp_small_kernel<kBlockSmall>;
+    a.max_it = max_it;
+    void (*kern)(const SmArgs) = level ? full_bp_small_kernel<kBlockSmall, true> : full_bp_small_kernel<kBlockSmall, false>;
     const size_t lds_bytes = 4u * (size_t)a.total;
     SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlockSmall), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
+}
+
+}  // namespace
+
+extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntrials,
+                                                   const uint16_t *d_vn_adj16, const uint16_t *d_cn_adj16,
+                                                   const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
+                                                   uint32_t *d_erased_bits, void *stream)
+{
+    return launch_small("scldpc_full_bp_fixpoint_device_cn16", false, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, 0,
+                        is_term, d_counters, d_erased_bits, stream);
+}
+
+// decodeBP with its iterations (count, cap MaxNumIt, stop tests): every counter of scldpc_full_bp_device, from both tables
+extern "C" int scldpc_full_bp_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                          const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it,
+                                          int32_t is_term, int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_small("scldpc_full_bp_device_cn16", true, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, max_it,
+                        is_term, d_counters, d_erased_bits, stream);
 }

@@ -290,6 +290,25 @@ def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=
     return {"counters": counters, "rows": None, "erased": erased}
 
 
+def full_bp_cn16(p, d_adj16, d_cn16, d_chan, max_it=0, is_term=True, want_erased=False, counters=None):
+    """scldpc_full_bp_device_cn16: decodeBP with its iterations (count, cap, stop tests) from the VN -> CN and CN -> VN
+    tables — every counter of full_bp (no trajectory rows)."""
+    _require_gpu()
+    T = d_adj16.shape[0]
+    assert d_adj16.is_cuda and d_adj16.dtype == torch.int16 and d_adj16.is_contiguous()
+    assert d_cn16.is_cuda and d_cn16.dtype == torch.int16 and d_cn16.is_contiguous()
+    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
+    assert tuple(d_adj16.shape[1:]) == (p.n, p.dv) and tuple(d_cn16.shape) == (T, p.nk, p.dc) and tuple(d_chan.shape) == (T, p.nw)
+    dev = d_adj16.device
+    if counters is None:
+        counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
+    erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
+    check(lib().scldpc_full_bp_device_cn16(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(),
+                                           int(max_it), 1 if is_term else 0, counters.data_ptr(),
+                                           erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    return {"counters": counters, "rows": None, "erased": erased}
+
+
 def cn_sockets(p, d_adj16, out=None):
     """scldpc_cn_sockets_device: the CN -> socket table int16 [T, nk, dc] (uint16 bit patterns) of a 2-byte VN -> CN table."""
     _require_gpu()

@@ -178,6 +178,12 @@ int scldpc_full_bp_fixpoint_device_adj16(const scldpc_code_params *p, int32_t nt
  *                                         chain end has fewer than dc (BPF:1703-1716).  Order within a CN unspecified (a set).
  *   scldpc_full_bp_fixpoint_device_cn16   counters of scldpc_full_bp_fixpoint_device from both tables: 4 bits of LDS per CN,
  *                                         seven trials per CU in flight (full_bp_small.hip).
+ *   scldpc_full_bp_device_cn16            decodeBP WITH its iterations from the same tables and the same 4 bits per CN: one
+ *                                         flooding iteration per barrier round, so max_it (MaxNumIt, BPF:1065; <= 0 = unlimited),
+ *                                         the stop tests (BPF:1044-1045) and SCLDPC_C_ITERATIONS / SCLDPC_C_STATUS are the
+ *                                         reference's — every counter of scldpc_full_bp_device (no trajectory rows), six
+ *                                         trials per CU in flight.  The reference's bp_lim_iter with a binding MAX_IT
+ *                                         (the published ..._500it_... / ..._1000it_... tables) runs on this one.
  *   scldpc_sample_philox_device_sock16    the same sampler emitting, instead of the CN -> VN table, the CN -> socket table
  *                                         d_cn_sock16 of scldpc_sw_bp_ring_device below (what scldpc_cn_sockets_device
  *                                         builds in a second pass); sockets are position-local, so any chain length.
@@ -194,6 +200,9 @@ int scldpc_full_bp_cn16_supported(const scldpc_code_params *p);
 int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
                                         const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t is_term,
                                         int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+int scldpc_full_bp_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                               const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                               int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
 
 /* decodeBP_SW, square window (BPW:628-912): window of W positions, init_it iterations for the
  * first window and max_it for the others (init_it == 0 ⇒ max_it, BPW:2101-2102). */

@@ -170,6 +170,9 @@ def test_second_generation_entry_points_refuse_what_they_do_not_take(L):
     assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 0, 0.5, 0, None, None, None, None, None) == 0      # empty batch
     assert L.scldpc_sample_philox_device_cn16(C.byref(base), 1, 0, 4, 0.5, 0, None, None, None, None, None) == -1     # null buffers
     assert L.scldpc_full_bp_fixpoint_device_cn16(C.byref(base), 4, None, None, None, 1, None, None, None) == -1
+    assert L.scldpc_full_bp_device_cn16(C.byref(long_), 4, None, None, None, 0, 1, None, None, None) == -2
+    assert L.scldpc_full_bp_device_cn16(C.byref(base), 4, None, None, None, 500, 1, None, None, None) == -1
+    assert L.scldpc_full_bp_device_cn16(C.byref(base), 0, None, None, None, 500, 1, None, None, None) == 0
     # window decoder with the window's state in LDS: (4,8) chains with 16-bit sockets, any window that fits
     assert L.scldpc_sw_bp_ring_supported(C.byref(big), 10) == 1 and L.scldpc_sw_bp_ring_supported(C.byref(base), 20) == 1
     assert L.scldpc_sw_bp_ring_supported(C.byref(odd), 5) == 0 and L.scldpc_sw_bp_ring_supported(C.byref(base), 0) == 0

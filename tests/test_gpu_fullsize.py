@@ -37,6 +37,9 @@ def big_run():
         fix = E.full_bp_fixpoint(p, d_a16, d_ch2)["counters"].cpu().numpy()
         assert (small[:, KEEP] == cnts[-1][:, KEEP]).all(), b
         assert (fix[:, KEEP] == cnts[-1][:, KEEP]).all(), b
+        # `bench.py --flooding` / bp_lim_iter with a cap: the 4-bit decoder walked one flooding iteration per round —
+        # ALL eight counters of every trial, the iteration count among them
+        assert torch.equal(E.full_bp_cn16(p, d_a16, d_cn16, d_ch2)["counters"], out["counters"]), b
         if b == 0:
             assert (E.adj16_to_global(p, d_a16[::500].cpu().numpy()) == d_adj[::500].cpu().numpy()).all()
             # properties on the first batch

@@ -95,6 +95,74 @@ def test_small_decoder_on_reference_fixtures(E, name):
         assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
 
 
+# ---- the same decoder walked one flooding iteration per barrier round (scldpc_full_bp_device_cn16) ------------------------
+@pytest.mark.parametrize("L,N,eps,is_term,caps", [
+    (50, 1000, 0.48, True, (0, 1, 2, 3, 40, 150, 233, 400)), (50, 1000, 0.45, True, (0, 25, 90)),
+    (50, 1000, 0.49, False, (0, 5, 120)), (50, 1000, 0.30, True, (0, 2)), (50, 1000, 0.10, True, (0, 1)),
+    (16, 200, 0.47, True, (0, 7)), (9, 24, 0.5, False, (0, 2)), (12, 1024, 0.46, True, (0, 30)),
+    (30, 400, 0.44, False, (0, 11)), (10, 10, 0.48, True, (0, 1)), (6, 16, 0.9, True, (0, 3)), (6, 16, 0.0, True, (0,)),
+    (60, 1000, 0.485, True, (0, 77))])
+def test_level_decoder_equals_flooding_kernel_counter_for_counter(E, L, N, eps, is_term, caps):
+    """full_bp_cn16 (4-bit counts, CN -> VN table, one flooding iteration per round) against full_bp (16-bit CN words): ALL
+    eight counters — the iteration count and the status among them — and the residual pattern, with and without binding
+    iteration caps (a capped run stops mid-way: the residual is the reference's a-posteriori erasure set of that iteration)."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 96 if N >= 1000 else 192
+    a, cn, ch = E.sample_philox_cn16(p, 78, 5000, T, eps)
+    for max_it in caps:
+        ref = E.full_bp(p, a, ch, max_it=max_it, is_term=is_term, want_erased=True)
+        lvl = E.full_bp_cn16(p, a, cn, ch, max_it=max_it, is_term=is_term, want_erased=True)
+        torch.cuda.synchronize()
+        r, v = ref["counters"].cpu().numpy(), lvl["counters"].cpu().numpy()
+        assert (r == v).all(), (max_it, np.argwhere(r != v)[:4].tolist(), r[r != v][:4], v[r != v][:4])
+        assert torch.equal(ref["erased"], lvl["erased"]), max_it
+        if max_it:
+            assert (v[:, 5] <= max_it).all()
+
+
+@pytest.mark.parametrize("name", golden_names(prefixes=("c2_", "mid_", "tiny_", "ss2_"), variants=("bpf", "bpt")))
+def test_level_decoder_on_reference_fixtures(E, name):
+    """The reference's own graphs and channels (glibc replay on the fixture's seeds), CN -> VN table built on the host:
+    counters, residual patterns and — where the fixture holds the trajectory rows — the iteration count, including the
+    fixtures generated with a binding MAX_IT (*_it1, _it3, _it5, _it100) and the truncated chains (BPT is_term = 0)."""
+    import torch
+    g = load_golden(name)
+    m = g.meta
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
+    T = min(g.T, 16 if p.n > 10000 else 64)
+    adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])
+    a16 = E.global_to_adj16(p, adj)
+    cn16 = E.cn_adj_from_vn_adj(p, a16)
+    d_a, d_ch = E.to_device(a16, ch)
+    d_cn = torch.from_numpy(cn16).to(d_a.device)
+    out = E.full_bp_cn16(p, d_a, d_cn, d_ch, max_it=g.max_it, is_term=bool(m["is_term"]), want_erased=True)
+    torch.cuda.synchronize()
+    c = out["counters"].cpu().numpy()
+    for col, key in ((0, "ne"), (1, "be"), (2, "ee"), (3, "bee"), (7, "nch")):
+        assert (c[:, col] == g[key][:T]).all(), (name, key)
+    assert (c[:, 6] == 0).all() and (c[:, 4] == 0).all()
+    er = E.unpack_bits(out["erased"].cpu().numpy(), p.n)
+    assert (er.sum(axis=1) == g["ne"][:T]).all()
+    if g.has("erased"):
+        assert (er == g["erased"][:T]).all()
+    if g.has("rows"):
+        assert [int(x) for x in c[:, 5]] == [len(g.rows_of(t)) for t in range(T)], name
+
+
+def test_level_decoder_with_a_small_queue_takes_the_frontier_from_the_snapshot(E):
+    """Low eps: nearly every erased VN is resolved in iteration 0, so the first frontier is several queue-fulls and the
+    pushes of one round overflow the queue (scan rounds back to back) — counters still equal the flooding kernel's."""
+    import torch
+    p = E.make_params(4, 8, 50, 1000)
+    for eps in (0.2, 0.35, 0.6, 0.97):
+        a, cn, ch = E.sample_philox_cn16(p, 79, 0, 64, eps)
+        ref = E.full_bp(p, a, ch, want_erased=True)
+        lvl = E.full_bp_cn16(p, a, cn, ch, want_erased=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ref["counters"], lvl["counters"]) and torch.equal(ref["erased"], lvl["erased"]), eps
+
+
 # ---- square window with only the window's state on chip (sw_ring.hip) ---------------------------------------------------
 @pytest.mark.parametrize("L,N,W,max_it,init_it,eps", [
     (100, 2000, 10, 20, 0, 0.47), (50, 1000, 20, 6, 60, 0.465), (50, 1000, 10, 20, 0, 0.47), (16, 200, 5, 3, 9, 0.45),
