@@ -122,8 +122,7 @@ class Simulator:
         self.dist, self.rank, self.world = _dist()
         if not shard_frames:                    # ε points are sharded by the caller: every point runs on one rank
             self.dist, self.rank, self.world = None, 0, 1
-        self.device = torch.device(device if device is not None else
-                                   "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        self.device = torch.device(device) if device is not None else E.local_device()
         if rng == "glibc":
             if self.world != 1:
                 raise ValueError("rng='glibc' replays one sequential reference stream: single rank only")
@@ -411,14 +410,10 @@ def main(prog, argv=None):
     opts = _parser(prog).parse_args(argv)
     if opts.seed is None:
         opts.seed = int((time.time() % 1) * 1e6)                      # te.tv_usec (BPF:2061)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+    joined = E.init_distributed()                                     # one process per GPU under torch.distributed.run
     extra = getattr(opts, "INIT_IT", None) if prog == "sw_lim_iter" else getattr(opts, "IS_TERM", None)
     rc = run_program(prog, opts.INDEX, opts.W, opts.NUM_DOPED, opts.MAX_IT, extra, opts)
-    if world > 1:
+    if joined:
         import torch.distributed as dist
         dist.destroy_process_group()
     return rc
@@ -468,7 +463,7 @@ def run_streaming(index, W, doped, opts):
                     opts.eps_delta if opts.eps_delta is not None else g0.eps_delta,
                     opts.num_points if opts.num_points else g0.num_points, 0, 0)
     dist, rank, world = _dist()
-    device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+    device = E.local_device()
     os.makedirs(opts.outdir, exist_ok=True)
     path = os.path.join(opts.outdir, stream_filename(p, len(doped), W, index))
     for sim in range(grid.num_points):
@@ -518,13 +513,9 @@ def streaming(argv=None):
         opts.seed = int((time.time() % 1) * 1e6)
     if len(opts.DOPED) < opts.NUM_DOPED:
         raise SystemExit("NUM_DOPED=%d but only %d positions given" % (opts.NUM_DOPED, len(opts.DOPED)))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+    joined = E.init_distributed()
     rc = run_streaming(opts.INDEX, opts.W, opts.DOPED[:opts.NUM_DOPED], opts)
-    if world > 1:
+    if joined:
         import torch.distributed as dist
         dist.destroy_process_group()
     return rc

@@ -6,6 +6,7 @@ channel_doped (sampling), decodeBP / decodeBP_SW (decoding), plr_computation / w
 accumulation).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -137,6 +138,33 @@ def sample_philox(p, seed, trial0, ntrials, eps, doped=(), device="cuda:0", out=
     check(fn(C.byref(p), int(seed), int(trial0), int(ntrials), float(eps), darr.size, dptr, d_adj.data_ptr(),
              d_ch.data_ptr(), ws, wsb, _stream_ptr(d_adj.device)))
     return d_adj, d_ch
+
+
+def local_device():
+    """This rank's GPU: cuda:LOCAL_RANK, as torch.distributed.run numbers the processes of a node.  In the rehearsal mode of
+    the tests (SCLDPC_DIST_BACKEND set to something other than nccl) ranks may share a GPU: LOCAL_RANK wraps around."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SCLDPC_DIST_BACKEND", "nccl") != "nccl":
+        local %= max(1, torch.cuda.device_count())
+    return torch.device("cuda", local)
+
+
+def init_distributed():
+    """Under torch.distributed.run (WORLD_SIZE > 1) join the job: one process per GPU, RCCL (backend "nccl") over xGMI.
+    Returns True when this call created the process group (the caller then destroys it).  SCLDPC_DIST_BACKEND=gloo is the
+    tests' rehearsal of the multi-rank drivers on a box with fewer GPUs than ranks."""
+    import torch.distributed as dist
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or dist.is_initialized():
+        return False
+    _require_gpu()
+    dev = local_device()
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("SCLDPC_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    return True
 
 
 def cn16_supported(p):

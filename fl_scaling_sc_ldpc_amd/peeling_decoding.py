@@ -116,7 +116,7 @@ def _dist():
 
 def _device(device):
     """Default device: this rank's GPU (LOCAL_RANK), as torch.distributed.run sets it."""
-    return device if device is not None else "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    return device if device is not None else str(E.local_device())
 
 
 def _split(total, world):
@@ -431,9 +431,51 @@ def _safe_eval(text):
     return ev(ast.parse(text, mode="eval"))
 
 
+def _cli_options(args, kw):
+    """The reference's command lines are positional only.  This mirror also takes, anywhere among them,
+    `--rng philox|numpy`, `--seed S`, `--batch B`, `--device D` — the keyword arguments of the simulators (throughput mode:
+    device sampling, trials sharded over the ranks of a torch.distributed.run job)."""
+    kw, pos, it = dict(kw), [], iter(args)
+    for x in it:
+        if isinstance(x, str) and x in ("--rng", "--seed", "--batch", "--device"):
+            v = next(it)
+            kw[x[2:]] = v if x in ("--rng", "--device") else int(v)
+        else:
+            pos.append(x)
+    return pos, kw
+
+
 def main_simulate_sc_ldpc(argv=None, **kw):
     """ber_sim.py: OUT l r L M "es" T|N U|P B|N TB|NTB num_repeats max_fuckups "doping" (PD:1327-1356)."""
-    a = sys.argv if argv is None else [None] + list(argv)
+    a, kw = _cli_options(sys.argv if argv is None else [None] + list(argv), kw)
+    joined = E.init_distributed() if kw.get("rng") == "philox" else False
+    try:
+        return _main_simulate_sc_ldpc(a, kw)
+    finally:
+        if joined:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+class _Tee:
+    """Rank 0 writes the table; the other ranks of a job compute the same rows (the counters are all-gathered) and stay silent."""
+
+    def __init__(self, path, active):
+        self.f = open(path, "wt") if active else None
+
+    def line(self, *vals):
+        if self.f is not None:
+            print(*vals, file=self.f)
+            print(*vals)
+            self.f.flush()
+            sys.stdout.flush()
+
+    def close(self):
+        if self.f is not None:
+            self.f.close()
+
+
+def _main_simulate_sc_ldpc(a, kw):
     fname, l, r, L, M = a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5])
     es = _safe_eval(a[6])
     is_terminated, is_protograph = a[7] == "T", a[8] == "P"
@@ -444,24 +486,32 @@ def main_simulate_sc_ldpc(argv=None, **kw):
     head = (f"# SC-LDPC ({l},{r},L={L},M={M}) terminated:{is_terminated}, proto:{is_protograph}, bounded:{is_bounded}, "
             f"tail biting:{is_tail_biting}. num_repeats={num_repeats}, max_fuckups={max_fuckups}, "
             f"doping_points={doping_points}.")
-    with open(fname, "wt") as f:
-        print(head)
-        print(head, file=f)
-        f.flush()
+    out = _Tee(fname, _dist()[1] == 0)
+    try:
+        out.line(head)
         for e in (es if isinstance(es, (list, np.ndarray, range)) else [es]):
             ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, _flrs, _gens, fblocks, tblocks, bler = \
                 simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is_tail_biting, num_repeats,
                                  max_fuckups, doping_points, **kw)
-            print(e, ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, fblocks, tblocks, bler, file=f)
-            print(e, ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, fblocks, tblocks, bler)
-            f.flush()
-            sys.stdout.flush()
+            out.line(e, ber, ber_truncated, plr, plr_exp, fbl, tbl, fbit, tgen, fblocks, tblocks, bler)
+    finally:
+        out.close()
 
 
 def main_simulate_variance(argv=None, **kw):
     """simulate_variance.py: OUT l r L M e T|N U|P num_runs num_runs_batch THEORY (PD:1264-1294): writes
     pickle.dump((ssquares, counts))."""
-    a = sys.argv if argv is None else [None] + list(argv)
+    a, kw = _cli_options(sys.argv if argv is None else [None] + list(argv), kw)
+    joined = E.init_distributed() if kw.get("rng") == "philox" else False
+    try:
+        return _main_simulate_variance(a, kw)
+    finally:
+        if joined:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def _main_simulate_variance(a, kw):
     fname, l, r, L, M, e = a[1], int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6])
     is_terminated, is_protograph = a[7] == "T", a[8] == "P"
     num_runs, num_runs_batch, ftheory = int(a[9]), int(a[10]), a[11]
@@ -477,8 +527,9 @@ def main_simulate_variance(argv=None, **kw):
         ss, cn = nu_chunk_from_moments(mom, r1s_theory, M)
         ssquares = ss if ssquares is None else ssquares + ss
         counts = cn if counts is None else counts + cn
-    with open(fname, "wb") as f:
-        pickle.dump((ssquares, counts), f)
+    if _dist()[1] == 0:                                                     # every rank holds the same sums: rank 0 writes
+        with open(fname, "wb") as f:
+            pickle.dump((ssquares, counts), f)
     return ssquares, counts
 
 
