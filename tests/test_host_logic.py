@@ -95,3 +95,14 @@ def test_module_entry_points_parse_their_argv():
     r = subprocess.run([sys.executable, "-m", "fl_scaling_sc_ldpc_amd.bp_decoding", "nonsense"], cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "usage" in r.stderr
+
+
+def test_peeling_cli_options_are_separated_from_the_reference_positionals():
+    """ber_sim.py / simulate_variance.py take positional arguments only (PD:1328-1340, 1265-1275); the mirror's extra
+    --rng/--seed/--batch/--device may stand anywhere among them and become keyword arguments of the simulators."""
+    from fl_scaling_sc_ldpc_amd import peeling_decoding as PD
+    pos, kw = PD._cli_options([None, "out.dat", "4", "--rng", "philox", "8", "50", "--seed", "7", "1000", "--batch", "256"], {"device": "cuda:1"})
+    assert pos == [None, "out.dat", "4", "8", "50", "1000"]
+    assert kw == {"device": "cuda:1", "rng": "philox", "seed": 7, "batch": 256}
+    pos, kw = PD._cli_options([None, "a", "b"], {})
+    assert pos == [None, "a", "b"] and kw == {}
