@@ -98,6 +98,57 @@ def sample_trial(rs, e, l, r, L, M, doping_points=(), is_protograph=False, is_ta
 # ------------------------------------------------------------------------------------------------
 # sweep peeling + error statistics (PD:270-313, 591-701, 1077-1095)
 # ------------------------------------------------------------------------------------------------
+def sic_round_literal(schedule, users, t):
+    """sic_round + subtract_interference (PD:270-313) restated on plain data: schedule = {slot: set(uid)},
+    users = {uid: {"transmissions": [...], "k": k, "recovered": set()}} (the reference's User tuple, PD:50-51; a user is
+    recovered once it has been seen alone in k slots, PD:255-256 — k = 1 for every user of the SC-LDPC path, PD:160).
+    Mutates both like the reference; returns the set of uids decoded in this round.  Small cases only: this is the literal
+    form that the reference's own known-answer case (test_2_6_csa_sync, PD:1164-1175) pins; peel_closure below is the
+    array form every other test uses, and tests/test_pd_oracle.py ties the two together."""
+    decoded = set()
+    if t not in schedule or len(schedule[t]) != 1:                        # PD:273-274
+        return decoded
+    rec = lambda us: {u for u in us if len(users[u]["recovered"]) >= users[u]["k"]}      # PD:251-256
+    single = next(iter(schedule[t]))
+    users[single]["recovered"].add(t)                                     # decode_slice, PD:259-261
+    ds = rec(schedule[t])
+    decoded |= ds
+    while ds:                                                             # PD:281-286
+        d = ds.pop()
+        revealed = set()
+        for slot_idx in users[d]["transmissions"]:                        # subtract_interference, PD:294-313
+            if slot_idx not in schedule:
+                continue
+            slot = schedule[slot_idx]
+            slot.remove(d)
+            if len(slot) == 1 and slot_idx <= t:                          # "we can not decode transmissions in the future"
+                users[next(iter(slot))]["recovered"].add(slot_idx)
+                revealed |= slot
+            if len(slot) == 0:
+                schedule.pop(slot_idx)
+        revealed = rec(revealed)
+        ds |= revealed
+        decoded |= revealed
+    return decoded
+
+
+def sweep_literal(tr, mask, total_size, sweep_start):
+    """`for t in range(sweep_start, total_size): sic_round(schedule, t)` (PD:656-657) with the literal round above on the
+    erased VNs of (tr, mask), k = 1: the boolean array of VNs still in the schedule — what peel_closure computes."""
+    users = {int(j): {"transmissions": [int(c) for c in tr[j]], "k": 1, "recovered": set()} for j in np.flatnonzero(mask)}
+    schedule = {}
+    for j, u in users.items():                                            # add_to_schedule, PD:328-334
+        for c in u["transmissions"]:
+            schedule.setdefault(c, set()).add(j)
+    for t in range(sweep_start, total_size):
+        sic_round_literal(schedule, users, t)
+    alive = np.zeros(len(mask), dtype=bool)
+    for us in schedule.values():
+        for j in us:
+            alive[j] = True
+    return alive
+
+
 def peel_closure(tr, mask, total_size, sweep_start):
     """Residual of `for t in range(sweep_start, total_size): sic_round(schedule, t)` (PD:656-657).
     A CN fires when it is swept holding exactly one VN (PD:273-277) or when a removal leaves it with exactly one VN

@@ -8,12 +8,20 @@
  * decodeBP_SW_circular returned and the running counters (BPF:2015-2046).
  *
  * usage: ref_stream_* P seed eps W dump ndoped d0 d1 …      (P = positions to decode)
+ *        ref_stream_* kat      runs the reference's own two table printers for this mode, test_is_position_doped_streaming
+ *                              and test_circular_buffer_wrapping (BPF:1891-1924): its only known-answer material here
  */
 #undef main
 #include <stdint.h>
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && argv[1][0] == 'k') {
+        test_is_position_doped_streaming();
+        printf("----\n");
+        test_circular_buffer_wrapping();
+        return 0;
+    }
     if (argc < 7) { fprintf(stderr, "usage: %s P seed eps W dump ndoped [d0 ...]\n", argv[0]); return 2; }
     int P = atoi(argv[1]);
     unsigned seed = (unsigned)strtoul(argv[2], 0, 10);

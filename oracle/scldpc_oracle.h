@@ -120,6 +120,10 @@ void orc_sample_philox(const orc_params *p, uint64_t seed, uint64_t trial, doubl
 int64_t orc_random_pick_philox(const int32_t *tr, const uint8_t *mask, int n, int l, int ncn, int total_size,
                                int num_steps, uint64_t seed, uint64_t trial, int64_t *r1_out);
 
+/* Streaming mode, the two helpers the reference's own table printers exercise (BPF:1891-1924; scldpc_stream_oracle.c) */
+int orc_stream_is_doped(int pos, int ndoped, const int32_t *doped);
+void orc_stream_sw_range(int pos, int L, int W, int ms, int32_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

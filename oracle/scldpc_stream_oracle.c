@@ -38,13 +38,34 @@ typedef struct orc_stream {
     int32_t ne, be, ee, bee, gb, gbl, gbe, gble;
 } orc_stream;
 
-static int is_doped(const orc_stream *s, int pos)                       /* BPF:1589-1612 */
+/* is_position_doped_streaming (BPF:1589-1612): the doping pattern repeats with period last_doped + 1 */
+int orc_stream_is_doped(int pos, int ndoped, const int32_t *doped)
 {
-    if (s->ndoped == 0) return 0;
-    int left = s->doped[0], period = s->doped[s->ndoped - 1] + 1, m = pos % period;
+    if (ndoped == 0) return 0;
+    int left = doped[0], period = doped[ndoped - 1] + 1, m = pos % period;
     if (m < left) return 0;
-    for (int i = 0; i < s->ndoped; i++) if (s->doped[i] == m) return 1;
+    for (int i = 0; i < ndoped; i++) if (doped[i] == m) return 1;
     return 0;
+}
+
+/* calc_sw_range_circular_vn / _cn (BPF:1169-1218): the window of stream position pos inside the circular buffer.
+ * out = { start_vn, end_vn, end_vn_wrap, is_wrap_vn, start_cn, end_cn, end_cn_wrap, is_wrap_cn } (positions) */
+void orc_stream_sw_range(int pos, int L, int W, int ms, int32_t out[8])
+{
+    const int posW = pos % L;
+    int sc = posW, ec = posW + W, ecw = 0, wc = 0;
+    if (ec > L) { wc = 1; ecw = (pos + W) % L; ec = L; }
+    int sv, ev, evw = 0, wv = 0;
+    if (pos <= ms) { sv = 0; ev = posW + W; }
+    else { sv = (pos - ms) % L; ev = sv + ms + W; if (ev > L) { wv = 1; evw = (pos + W) % L; ev = L; } }
+    out[0] = sv; out[1] = ev; out[2] = evw; out[3] = wv; out[4] = sc; out[5] = ec; out[6] = ecw; out[7] = wc;
+}
+
+static int is_doped(const orc_stream *s, int pos)
+{
+    int32_t d[32];
+    for (int i = 0; i < s->ndoped; i++) d[i] = s->doped[i];
+    return orc_stream_is_doped(pos, s->ndoped, d);
 }
 
 typedef struct { uint32_t key; int32_t sock; } skeyed;
@@ -205,12 +226,9 @@ static int deg_two_ss(const orc_stream *s, int slot)                    /* get_d
 static int decode_pos(orc_stream *s, int pos)
 {
     const int L = s->p.L, dv = s->p.dv, dc = s->p.dc, V = s->p.vns_pos, C = s->p.cns_pos, ms = dv - 1, W = s->W;
-    const int posW = pos % L;
-    int sc = posW, ec = posW + W, ecw = 0;                                /* calc_sw_range_circular_cn BPF:1169-1185 */
-    if (ec > L) { ecw = (pos + W) % L; ec = L; }
-    int sv, ev, evw = 0;                                                 /* calc_sw_range_circular_vn BPF:1188-1218 */
-    if (pos <= ms) { sv = 0; ev = posW + W; }
-    else { sv = (pos - ms) % L; ev = sv + ms + W; if (ev > L) { evw = (pos + W) % L; ev = L; } }
+    int32_t rg[8];
+    orc_stream_sw_range(pos, L, W, ms, rg);                              /* BPF:1169-1218 */
+    const int sv = rg[0], ev = rg[1], evw = rg[2], sc = rg[4], ec = rg[5], ecw = rg[6];
     const int j0 = sv * V, j1 = ev * V, j1w = evw * V, c0 = sc * C, c1 = ec * C, c1w = ecw * C;
     int prec = s->n, nep = 0;
     for (;;) {

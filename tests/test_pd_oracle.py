@@ -137,3 +137,35 @@ def test_calc_nu_chunk_equals_the_reference(path):
     mom = np.stack([(r1s != 0).sum(0), r1s.sum(0), (r1s ** 2).sum(0)]).astype(np.int64)
     ss2, cnt2 = PD.nu_chunk_from_moments(mom, th, M)
     assert (cnt2 == z["counts"]).all() and np.allclose(ss2, z["ssquares"], rtol=1e-12, atol=1e-300)
+
+
+def test_literal_sic_round_reproduces_the_reference_known_answer_case():
+    """test_2_6_csa_sync (PD:1164-1175), the one hand-built known-answer case the reference holds for sic_round: three users
+    with k = 2 over ten slots; nothing is decoded for t = 0..9, all three at t = 10, and the schedule ends empty
+    (tests/golden/kat_reference.json: the reference's own functions run on its own data by oracle/make_golden_kat.py)."""
+    from oracle import pd_oracle as P
+    kat = json.load(open(os.path.join(GOLDEN_DIR, "kat_reference.json")))["csa_2_6_sync"]
+    users = {u["uid"]: {"transmissions": list(u["transmissions"]), "k": u["k"], "recovered": set()} for u in kat["users"]}
+    schedule = {}
+    for uid, u in users.items():
+        for c in u["transmissions"]:
+            schedule.setdefault(c, set()).add(uid)
+    got = [sorted(P.sic_round_literal(schedule, users, t)) for t in range(11)]
+    assert got == kat["decoded_at_t"] and got[10] == [1, 2, 3]
+    assert {str(k): sorted(v) for k, v in schedule.items()} == kat["schedule_left"] == {}
+    assert {str(uid): sorted(u["recovered"]) for uid, u in users.items()} == kat["recovered"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_array_closure_equals_the_literal_sweep(seed):
+    """peel_closure (what every other test and the device twin rest on) == the literal sic_round sweep pinned above, on
+    random small chains: terminated and not, bounded and not (sweep start > 0), CNs beyond total_size that never fire."""
+    from oracle import pd_oracle as P
+    rs = np.random.RandomState(100 + seed)
+    l, r, L, M = 4, 8, 6 + seed % 5, 8 + 4 * (seed % 3)
+    tr = P.gen_slots(rs, l, r, L, M)
+    mask = P.gen_erasures(rs, 0.35 + 0.05 * (seed % 6), l, r, L, M)
+    cpp = M * l // r
+    ncn = int(tr.max()) + 1
+    for total_size, start in ((ncn, 0), (cpp * L, 0), (cpp * L, 2 * cpp), (ncn, cpp)):
+        assert (P.peel_closure(tr, mask, total_size, start) == P.sweep_literal(tr, mask, total_size, start)).all()

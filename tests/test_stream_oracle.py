@@ -45,3 +45,28 @@ def test_streaming_fresh_seeds_against_reference(oracle):
             for k in range(90):
                 o = s.step()
                 assert all(o[f] == ref[k][f] for f in oracle.Stream.FIELDS), (seed, eps, W, doped, dec, k)
+
+
+def test_stream_helpers_reproduce_the_reference_table_printers(oracle):
+    """test_is_position_doped_streaming and test_circular_buffer_wrapping (BPF:1891-1924): the reference's own (print-only)
+    known-answer tables for the streaming mode, captured from the compiled reference by oracle/make_golden_kat.py.  The
+    oracle's decoder takes its doping test and its window ranges from exactly these two functions."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    kat = json.load(open(os.path.join(GOLDEN_DIR, "kat_reference.json")))
+    L = oracle.lib()
+    d = kat["is_position_doped_streaming"]
+    doped = (C.c_int32 * len(d["doped_positions"]))(*d["doped_positions"])
+    assert len(d["pos_is_doped"]) == 30
+    for pos, want in d["pos_is_doped"]:
+        assert L.orc_stream_is_doped(pos, len(d["doped_positions"]), doped) == want, pos
+    assert L.orc_stream_is_doped(17, 0, doped) == 0
+    w = kat["circular_buffer_wrapping"]
+    assert len(w["rows"]) == 80
+    out = (C.c_int32 * 8)()
+    for pos, kind, start, end, end_wrap, is_wrap in w["rows"]:
+        L.orc_stream_sw_range(pos, w["L"], w["W"], w["ms"], out)
+        got = list(out[0:4]) if kind == "VN" else list(out[4:8])
+        assert got == [start, end, end_wrap, is_wrap], (pos, kind, got)
