@@ -37,14 +37,23 @@ def _risultati(name):
     return [dict(eps=r[0], f=int(r[9]), users=int(r[10]), fail=int(r[11]), blocks=int(r[12])) for r in t]
 
 
-def _pick(rows, lo=0.004, hi=0.996, every=2):
-    """rows in the waterfall (the floor and the saturated end carry no information at these sample sizes), every other one"""
-    sel = [r for r in rows if lo <= r["fail"] / r["f"] <= hi and r["fail"] >= 300]
-    return sel[::every]
+def _pick(rows, lo=0.004, hi=0.996):
+    """every row in the waterfall (the floor and the saturated end carry no information at these sample sizes)"""
+    return [r for r in rows if lo <= r["fail"] / r["f"] <= hi and r["fail"] >= 300]
 
 
 def _trials_for(fer):
-    return int(min(196608, max(32768, -(-1200 / fer // BATCH) * BATCH)))
+    return int(min(262144, max(32768, -(-2000 / fer // BATCH) * BATCH)))
+
+
+REPORT = os.environ.get("SCLDPC_CURVES_REPORT")       # a file to append "what eps published ours z" lines to (profiles/)
+
+
+def _report(what, eps, f_pub, p_pub, T, p_our, z):
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write("%-24s eps=%.5f  published FER %.6f (%7d frames)   here %.6f (%7d trials)   z = %+.2f\n"
+                    % (what, eps, p_pub, f_pub, p_our, T, z))
 
 
 class _Acc:
@@ -67,6 +76,7 @@ def _compare(acc, row, what):
     p_pub, p_our = row["fail"] / row["f"], k / T
     pooled = (k + row["fail"]) / (T + row["f"])
     z = (p_our - p_pub) / np.sqrt(pooled * (1 - pooled) * (1 / T + 1 / row["f"]))
+    _report(what, row["eps"], row["f"], p_pub, T, p_our, z)
     assert abs(z) < SIGMAS, (what, row["eps"], "FER", p_our, p_pub, z)
     for name, s1, s2, pub in (("users", acc.s[0], acc.s[1], row["users"]), ("blocks", acc.s[2], acc.s[3], row["blocks"])):
         mean = s1 / k
@@ -130,7 +140,7 @@ def test_peeling_error_rates_reproduce_published_table(M):
     require_gpu()
     from fl_scaling_sc_ldpc_amd import peeling_decoding as PD
     t = np.loadtxt(os.path.join(PUB, f"terminated_fer_plr_sc_ldpc_4_8_50_{M}.dat"))
-    rows = [r for r in t if 0.01 <= r[1] / r[2] <= 0.99 and r[1] >= 300][::3]
+    rows = [r for r in t if 0.01 <= r[1] / r[2] <= 0.99 and r[1] >= 300][::2]
     assert len(rows) >= 3
     zs = []
     for i, r in enumerate(rows):
@@ -142,6 +152,7 @@ def test_peeling_error_rates_reproduce_published_table(M):
         assert trials == T and gen == T * 50 * M
         pooled = (fail + fail_pub) / (T + T_pub)
         z = (fail / T - fail_pub / T_pub) / np.sqrt(pooled * (1 - pooled) * (1 / T + 1 / T_pub))
+        _report(f"peeling N={M} FER_exp", eps, T_pub, fail_pub / T_pub, T, fail / T, z)
         assert abs(z) < SIGMAS, (M, eps, fail / T, fail_pub / T_pub, z)
         # lost users per failed frame: its spread is of the order of its mean (the residual is either one stalled wave
         # or most of the chain), so the standard error is bounded by mean * sqrt(1/k + 1/k_pub) * 1.5
