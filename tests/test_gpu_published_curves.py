@@ -49,11 +49,11 @@ def _trials_for(fer):
 REPORT = os.environ.get("SCLDPC_CURVES_REPORT")       # a file to append "what eps published ours z" lines to (profiles/)
 
 
-def _report(what, eps, f_pub, p_pub, T, p_our, z):
+def _report(what, eps, f_pub, p_pub, T, p_our, z, quantity="FER"):
     if REPORT:
         with open(REPORT, "a") as f:
-            f.write("%-24s eps=%.5f  published FER %.6f (%7d frames)   here %.6f (%7d trials)   z = %+.2f\n"
-                    % (what, eps, p_pub, f_pub, p_our, T, z))
+            f.write("%-30s eps=%.5f  published %s %.6f (%7d frames)   here %.6f (%7d frames)   z = %+.2f\n"
+                    % (what, eps, quantity, p_pub, f_pub, p_our, T, z))
 
 
 class _Acc:
@@ -160,3 +160,58 @@ def test_peeling_error_rates_reproduce_published_table(M):
         assert abs(m_our - m_pub) < SIGMAS * 1.5 * m_pub * np.sqrt(1 / fail + 1 / fail_pub), (M, eps, m_our, m_pub)
         zs.append(z)
     assert abs(np.mean(zs)) < SIGMAS / np.sqrt(len(zs)) + 0.5, zs
+
+
+@pytest.mark.parametrize("tag,frames,batch", [("L100_M500_e4550_trunc_1000it", 24576, 4096), ("L50_M2500_e4600_trunc_500it", 8192, 2048)])
+def test_bp_trajectories_reproduce_the_published_files_statistics(E, tag, frames, batch):
+    """bp_traj INDEX 0 0 MAX_IT 0 (BPT): the 2 x 100 000 published trajectories (sim_data/trajectories_bp_decoding, condensed
+    per iteration by oracle/make_golden_published_traj.py) against trajectories decoded here — at a ladder of iterations t the
+    fraction of frames still iterating (the distribution of the iteration count) and, over those frames, the mean of every
+    column the files hold: deg_1_iter (with its iteration-0 quirk, BPF:969-978), VNs recovered in the iteration (its first
+    value counts from n, BPF:910), first erased position (4-column files).  These files are what the reference's scaling-law
+    estimation reads (NB cells 40, 50)."""
+    import json
+    import torch
+    z = np.load(os.path.join(PUB, f"bp_trajectories_{tag}.npz"))
+    m = json.loads(str(z["meta"]))
+    n_pub, s1, s2, F_pub = z["n_t"], z["sum"], z["sumsq"], int(z["frames"])
+    cols = m["columns"] - 1
+    p = E.make_params(m["dv"], m["dc"], m["L"], m["vns_pos"])
+    cap = m["max_it"]
+    n_our = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    o1 = torch.zeros((3, cap), dtype=torch.float64, device="cuda")
+    o2 = torch.zeros((3, cap), dtype=torch.float64, device="cuda")
+    tt = torch.arange(cap, device="cuda")[None, :]
+    for b0 in range(0, frames, batch):
+        adj, ch = E.sample_philox(p, 4711, b0, batch, m["eps"], adj16=True)
+        out = E.full_bp(p, adj, ch, max_it=cap, is_term=bool(m["is_term"]), rows_cap=cap)
+        its = out["counters"][:, 5]
+        assert int(out["counters"][:, 6].min().item()) == 0 and int(its.max().item()) <= cap
+        live = (tt < its[:, None]).double()                               # [batch, cap]
+        rows = out["rows"].double()                                       # [batch, cap, 3]
+        n_our += live.sum(dim=0)
+        for c in range(3):
+            v = rows[:, :, c] * live
+            o1[c] += v.sum(dim=0)
+            o2[c] += (v * v).sum(dim=0)
+        del out, rows, live
+    n_our, o1, o2 = n_our.cpu().numpy(), o1.cpu().numpy(), o2.cpu().numpy()
+    assert n_our[0] == frames and n_pub[0] == F_pub == 100000
+    checked = 0
+    for t in (0, 1, 2, 3, 5, 8, 12, 20, 30, 45, 60, 80, 100, 125, 150, 175, 200, 230, 260, 300, 350, 400, 450, 500, 560):
+        if t >= cap or n_pub[t] < 3000 or n_our[t] < 600:
+            continue
+        pp, po = n_pub[t] / F_pub, n_our[t] / frames
+        pooled = (n_pub[t] + n_our[t]) / (F_pub + frames)
+        if 0 < pooled < 1:
+            zs = (po - pp) / np.sqrt(pooled * (1 - pooled) * (1 / F_pub + 1 / frames))
+            assert abs(zs) < SIGMAS, (tag, t, "frames still iterating", po, pp, zs)
+        for c in range(cols):
+            mp, mo = s1[c, t] / n_pub[t], o1[c, t] / n_our[t]
+            vp, vo = max(s2[c, t] / n_pub[t] - mp * mp, 0.0), max(o2[c, t] / n_our[t] - mo * mo, 0.0)
+            se = np.sqrt(vp / n_pub[t] + vo / n_our[t])
+            assert abs(mo - mp) <= SIGMAS * se + 1e-9, (tag, t, ("deg1", "recovered", "first erased position")[c], mo, mp, se)
+            _report(f"bp_traj {tag[:9]} t={t}", m["eps"], int(n_pub[t]), mp, int(n_our[t]), mo, (mo - mp) / se if se > 0 else 0.0,
+                    quantity=("mean deg_1_iter", "mean recovered", "mean first erased pos")[c])
+        checked += 1
+    assert checked >= 10, checked
