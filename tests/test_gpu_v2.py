@@ -246,3 +246,37 @@ def test_ring_window_decoder_on_reference_fixtures(E, name):
         assert (c[:, col] == g[k][:T]).all(), (name, k)
     if g.has("erased"):
         assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
+
+
+# ---- the reference's two decoder families on ONE graph ("cross-implementation redundancy") ------------------
+@pytest.mark.parametrize("L,N,eps,is_term", [(50, 1000, 0.48, True), (50, 1000, 0.47, False), (20, 200, 0.46, True),
+                                             (20, 200, 0.49, False), (12, 64, 0.5, True)])
+def test_bp_and_peeling_paths_leave_the_same_stopping_set_on_a_shared_graph(E, L, N, eps, is_term):
+    """On the BEC unlimited flooding BP (bp_decoding: decodeBP, BPF:900-1140) and peeling (peeling_decoding: the sic_round
+    sweep PD:270-313 and the random-pick peeling PD:740-785) all stop at the maximal stopping set of the erased VNs.  The
+    reference never runs its two simulators on a shared graph; here one batch of sampled codes and channels goes through the
+    four device decoders of both families: identical residual VN sets (flooding, fixpoint, sweep) and, for random-pick
+    peeling — whose picks are random but whose closure is not — the same number of VNs left."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 64
+    adj, ch = E.sample_philox(p, 321, 77, T, eps)                        # int32 global ids: the layout all four kernels take
+    total_size = p.nk if is_term else L * p.cns_pos                     # CNs beyond a truncated chain never fire (BPT:944-948, PD:609-611)
+    bp = E.full_bp(p, adj, ch, is_term=is_term, want_erased=True)
+    fx = E.full_bp_fixpoint(p, adj, ch, is_term=is_term, want_erased=True)
+    sw = E.peel_sweep(p, adj, ch, total_size, want_lost=True)
+    steps = p.n                                                          # more picks than erased VNs: runs to exhaustion
+    pk = E.peel_pick(p, adj, ch, total_size, steps, seed=5, trial0=0, want_r1=False)
+    torch.cuda.synchronize()
+    assert torch.equal(bp["erased"], fx["erased"])
+    ne = bp["counters"][:, 0]
+    # simulate_sc_ldpc counts as lost only users all of whose transmissions lie below total_size (PD:659-666): on a truncated
+    # chain the VNs of the last dv - 1 positions are outside its statistic, decodeBP's VNerased keeps them
+    counted = p.n if is_term else (L - (p.dv - 1)) * N
+    er = torch.from_numpy(E.unpack_bits(bp["erased"].cpu().numpy(), p.n)[:, :counted].copy())
+    lost = torch.from_numpy(E.unpack_bits(sw["lost"].cpu().numpy(), p.n))
+    assert torch.equal(er, lost[:, :counted]) and int(lost[:, counted:].sum()) == 0
+    assert torch.equal(er.sum(dim=1).to(torch.int32), sw["out"][:, 0].cpu()) and torch.equal(bp["counters"][:, 7], sw["out"][:, 7])
+    out = pk["out"]                                                      # [0] #erased, [1] #picked
+    assert torch.equal(out[:, 0], bp["counters"][:, 7]) and torch.equal(out[:, 0] - out[:, 1], ne)
+    assert int((ne > 0).sum().item()) > 0 or eps < 0.47                  # the batch does contain failures where expected
