@@ -30,7 +30,7 @@ namespace {
 using namespace scldpc_dev;
 
 constexpr int kBlock = 256;
-enum { R_NCH = 0, R_PUSH = 1, R_OVF = 4, R_REM = 7, R_N = 12 };      // PUSH / OVF / REM rotate three ways: one barrier per iteration
+enum { R_NCH = 0, R_PUSH = 1, R_OVF = 4, R_REM = 7, R_TMP = 10, R_N = 12 };      // PUSH / OVF / REM rotate three ways: one barrier per iteration
 
 struct RArgs {
     int dv, dc, L, V, C, n, nk, W, max_it, init_it, nw;
@@ -162,12 +162,51 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
     for (int qq = 0; qq < min(W, L); qq++) enter(qq);
 
     int iters_total = 0, gen = 0;
+    int carry_n = 0, phi_prev = 0;
+    bool carry_ok = false;                                                // the last round's queue is complete (no overflow)
     for (int posW = 0; posW < L; posW++) {
         const int phi = min(posW + W, D);                                 // CN positions [posW, phi)   (BPW:674-676)
         const int qhi = min(posW + W, L);                                 // VN positions [posW, qhi)   (BPW:691-693)
         const int cap = posW == 0 ? a.init_it : a.max_it;                 // BPW:699-702
         int iter = 0, prec = a.n, ncur = 0;
-        bool scan = true;                                                 // a window opens with a scan of its CNs
+        bool scan = true;                                                 // the first window opens with a scan of its CNs
+        if (carry_ok) {
+            // Later windows: the count-one CNs of [posW, phi) are (a) those the previous window's last round queued — a CN
+            // that held one erased neighbour earlier has fired since (count zero) or waits for a frozen VN for good — and
+            // (b) those of the one CN position that has just entered the window (never queued: pushes stop at phi), whose
+            // counts the VN position entered above has completed.  No snapshot needed: nothing is in flight here.
+            uint32_t *qc = q[gen & 1];
+            if (tid == 0) scal[R_TMP] = carry_n;
+            __syncthreads();
+            if (phi > phi_prev) {
+                const int pn = phi - 1;
+                for (int w0 = (tid >> 6) * 64; w0 < Cw; w0 += kBlock) {
+                    const int w = w0 + lane;
+                    uint32_t z = 0;
+                    if (w < Cw) {
+                        const uint32_t y = cnt[cslot(pn) + w] ^ 0x11111111u;
+                        z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+                    }
+                    const int mine = __popc(z);
+                    const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                    const int tot = __builtin_amdgcn_readlane(incl, 63);
+                    if (tot == 0) continue;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&scal[R_TMP], tot);
+                    int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+                    while (z) {
+                        const int k = (__ffs((int)z) - 1) >> 2;
+                        z &= z - 1;
+                        if (idx < qcap) qc[idx] = ((uint32_t)pn << 16) | (uint32_t)(w * 8 + k);
+                        idx++;
+                    }
+                }
+            }
+            __syncthreads();
+            const int tot = scal[R_TMP];
+            if (tot <= qcap) { ncur = tot; scan = false; }                // else the full scan below finds them all
+        }
+        phi_prev = phi;
         int term = 0;
         for (int qq = posW; qq < qhi; qq++) term += pos_cnt[qq];          // erasures inside the window (BPW:791-809)
         for (;;) {
@@ -177,7 +216,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
             if (tid == 0) { scal[R_PUSH + (gen + 2) % 3] = 0; scal[R_OVF + (gen + 2) % 3] = 0; scal[R_REM + (gen + 1) % 3] = 0; }
             int removed = 0;
             // CN (p, l) of the snapshot: release its lone erased neighbour unless that one is frozen
-            auto release = [&](int p, int l) {
+            // out[i] = 1 + [CN position | CN] of edge i if this release left that CN with one erased neighbour inside the window
+            auto release = [&](int p, int l, uint32_t (&out)[4]) {
+                if (p < posW) return;                                     // queued by the previous window for the position it left
                 const uint4 s4 = *reinterpret_cast<const uint4 *>(crow + ((size_t)p * C + l) * DC);
                 const uint32_t sk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
                                         s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
@@ -189,21 +230,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
                     if ((unsigned)qq < (unsigned)L && ((S[sslot(qq) + (t >> 5)] >> (t & 31)) & 1u)) { jq = qq; jt = t; }
                 }
                 if (jq < posW) return;                                    // none left (released this round) or frozen (BPW:745)
+                const uint2 r = vrow[(size_t)jq * V + jt];                // issued before the claim: overlaps its round trip
                 const uint32_t bit = 1u << (jt & 31);
                 if (!(atomicAnd(&S[sslot(jq) + (jt >> 5)], ~bit) & bit)) return;
                 atomicSub(&pos_cnt[jq], 1);
                 removed++;
-                const uint2 r = vrow[(size_t)jq * V + jt];
                 const uint32_t ll[4] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16};
+                uint32_t o[4];
 #pragma unroll
-                for (int i = 0; i < DV; i++) {
-                    const int sh = (ll[i] & 7) * 4;
-                    const uint32_t o = (atomicSub(&cnt[cslot(jq + i) + (ll[i] >> 3)], 1u << sh) >> sh) & 15u;
-                    if (o == 2u && jq + i < phi) {                        // 2 -> 1 inside the window: fires next iteration
-                        const int idx = atomicAdd(push, 1);
-                        if (idx < qcap) qn[idx] = ((uint32_t)(jq + i) << 16) | ll[i]; else *ovf = 1;   // [CN position | CN]
-                    }
-                }
+                for (int i = 0; i < DV; i++)                              // the dv returning atomics go out back to back
+                    o[i] = atomicSub(&cnt[cslot(jq + i) + (ll[i] >> 3)], 1u << ((ll[i] & 7) * 4));
+#pragma unroll
+                for (int i = 0; i < DV; i++)
+                    if (((o[i] >> ((ll[i] & 7) * 4)) & 15u) == 2u && jq + i < phi)       // 2 -> 1 inside the window: fires next iteration
+                        out[i] = 1u + (((uint32_t)(jq + i) << 16) | ll[i]);
+            };
+            // a wave appends its lanes' entries behind *push: one prefix scan + one LDS atomic per wave
+            auto append = [&](const uint32_t (&out)[4]) {
+                const int mine = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+                const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (tot == 0) return;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(push, tot);
+                int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (out[i]) { if (idx < qcap) qn[idx] = out[i] - 1u; else *ovf = 1; idx++; }
             };
             if (scan) {
                 // snapshot {c in the window : count == 1} first: this round's releases must not promote CNs into it
@@ -214,16 +267,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
                     }
                 __syncthreads();
                 for (int p = posW; p < phi; p++)
-                    for (int w = tid; w < Cw; w += kBlock) {
-                        uint32_t z = fbits[(p - posW) * Cw + w];
-                        while (z) {
-                            const int k = (__ffs((int)z) - 1) >> 2;
-                            z &= z - 1;
-                            if (w * 8 + k < C) release(p, w * 8 + k);
+                    for (int w0 = (tid >> 6) * 64; w0 < Cw; w0 += kBlock) {          // wave-uniform trip count (append scans)
+                        const int w = w0 + lane;
+                        uint32_t z = w < Cw ? fbits[(p - posW) * Cw + w] : 0u;
+                        while (__any(z != 0u)) {
+                            uint32_t out[4] = {0, 0, 0, 0};
+                            if (z) {
+                                const int k = (__ffs((int)z) - 1) >> 2;
+                                z &= z - 1;
+                                if (w * 8 + k < C) release(p, w * 8 + k, out);
+                            }
+                            append(out);
                         }
                     }
             } else {
-                for (int k = tid; k < ncur; k += kBlock) release((int)(qc[k] >> 16), (int)(qc[k] & 0xFFFFu));
+                for (int k0 = (tid >> 6) * 64; k0 < ncur; k0 += kBlock) {
+                    uint32_t out[4] = {0, 0, 0, 0};
+                    if (k0 + lane < ncur) release((int)(qc[k0 + lane] >> 16), (int)(qc[k0 + lane] & 0xFFFFu), out);
+                    append(out);
+                }
             }
             removed = wave_sum(removed);
             if (lane == 0 && removed) atomicAdd(rem, removed);
@@ -238,6 +300,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
             iter++;
             if (!(iter < cap)) break;                                     // BPW:839
         }
+        carry_ok = !scan;
+        carry_n = ncur;
         // position posW is decided (BPW:759-788): its S bits are VNerased from now on
         emit_erased(posW);
         if (posW + W < L) enter(posW + W);                                // the next window's new position
