@@ -17,8 +17,11 @@
 // CN -> socket table (uint16 [nk][dc], socket s = dv*t + i = edge i of VN t of position CNpos - i; built from the VN -> CN
 // table by scldpc_cn_sockets_device below) as the socket whose S bit is still set.
 //
-// One flooding iteration == one barrier round over a snapshot of the window's count-one CNs, so iteration caps (init_it /
-// max_it, BPW:699-702, 839) and the stop rule (window erasures zero or unchanged, BPW:815-816) are the reference's.
+// One flooding iteration == one barrier round over the CNs whose count was one when it began, so iteration caps (init_it /
+// max_it, BPW:699-702, 839) and the stop rule (window erasures zero or unchanged, BPW:815-816) are the reference's.  The
+// frontier is a queue: the CNs the previous round took from two to one, and — when the window moves on — those plus the
+// count-one CNs of the single CN position that entered the window (a scan of the whole window only opens the first window
+// and repairs a queue overflow).
 // Size-2 stopping sets (BPW:850-908: every failing position contributes): VN position q is examined when the window has
 // moved dv positions past it — then its dv CN positions are final and still in the ring; a qualifying partner lies in the
 // same position, so only S bits of position q are consulted.
