@@ -112,12 +112,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
         mine = wave_sum(mine);
         if (lane == 0 && mine) { atomicAdd(&pos_cnt[qq], mine); atomicAdd(&scal[R_NCH], mine); }
         __syncthreads();
-        for (int t = tid; t < V; t += kBlock) {
-            if (!((S[sslot(qq) + (t >> 5)] >> (t & 31)) & 1u)) continue;
-            const uint2 r = vrow[(size_t)qq * V + t];
-            const uint32_t l[4] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16};
+        // rows are loaded unconditionally, four per thread in flight (coalesced 8-byte loads), then the erased ones count
+        for (int t0 = tid; t0 < V; t0 += 4 * kBlock) {
+            uint2 r[4];
+            bool er[4];
 #pragma unroll
-            for (int i = 0; i < DV; i++) atomicAdd(&cnt[cslot(qq + i) + (l[i] >> 3)], 1u << ((l[i] & 7) * 4));
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u * kBlock;
+                er[u] = false;
+                if (t < V) { r[u] = vrow[(size_t)qq * V + t]; er[u] = (S[sslot(qq) + (t >> 5)] >> (t & 31)) & 1u; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!er[u]) continue;
+                const uint32_t l[4] = {r[u].x & 0xFFFFu, r[u].x >> 16, r[u].y & 0xFFFFu, r[u].y >> 16};
+#pragma unroll
+                for (int i = 0; i < DV; i++) atomicAdd(&cnt[cslot(qq + i) + (l[i] >> 3)], 1u << ((l[i] & 7) * 4));
+            }
         }
         __syncthreads();
     };
