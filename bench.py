@@ -374,7 +374,8 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
     L_CHAIN, N_POS = 50, 10000
     EPS = 0.48 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
-    B = a.batch or 8192                                 # one wave per trial: 32 waves per CU x 256 CUs in flight
+    B = a.batch or 16384                                # one wave per trial, 32 waves per CU x 256 CUs = 8192 in flight: two
+                                                        # rounds, the second fills the CUs the early finishers leave
     steps_pd = int(N_POS * L_CHAIN * (EPS + 0.1))       # PD:721 (non-terminated)
     total_size = p.cns_pos * L_CHAIN
     d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev)

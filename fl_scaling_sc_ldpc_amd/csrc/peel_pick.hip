@@ -17,6 +17,10 @@
 #include "kernel_util.h"
 #include "philox.h"
 
+#ifndef SCLDPC_PICK_SGPRS
+#define SCLDPC_PICK_SGPRS 80
+#endif
+
 namespace {
 
 using namespace scldpc_dev;
@@ -43,8 +47,10 @@ struct Args {
 using scldpc_dev::philox4x32_10;
 
 // G: CN words in the global workspace (ensembles beyond the LDS budget, e.g. the notebook's N = 10000)
+// Throughput = trials in flight, one wave each: the scalar file admits eight waves per SIMD only up to 80 SGPRs per wave
+// (⌊800 / (⌈sgpr/16⌉·16 + 16)⌋; uncapped the kernel takes 112 and six waves fit), the overflow lives in VGPR lanes.
 template <int DV, bool A16, bool G, bool D1G>
-__global__ __launch_bounds__(kBlock) void peel_pick_kernel(const Args a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_SGPRS))) void peel_pick_kernel(const Args a)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *cn;                                                         // ncn words
