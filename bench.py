@@ -164,9 +164,18 @@ def main():
                          "(default: sampler_v2 + the 4-bits-per-CN decoder, which also reads the CN -> VN table)")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` launched plainly (no launcher, no WORLD_SIZE): start the N ranks ourselves, as fresh child
+    # processes, BEFORE anything here touches the GPU (never an exec of this process), relay rank 0's one JSON line and the
+    # job's exit code.  Under a launcher (WORLD_SIZE set) a --gpus that disagrees with it is an error, not a note.
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...) "
+                         f"or run `python bench.py --gpus {a.gpus}` without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # One rank per GPU over RCCL.  Rehearsal on a box with fewer GPUs than ranks (tests/test_gpu_bench_ranks.py: two ranks
@@ -179,8 +188,8 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
+    global REHEARSAL, RCCL_RANKS
     if backend != "nccl" or world > ndev:
-        global REHEARSAL
         REHEARSAL = f"backend={backend}, {world} ranks on {ndev} device(s)"
     if world > 1:
         import torch.distributed as dist
@@ -188,8 +197,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        # one real all-reduce over the job's backend before anything is timed: every rank contributes 1, so the sum is the
+        # number of ranks that are really connected (RCCL over xGMI when backend == "nccl"); reported as `rccl_ranks`
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        if int(ones.item()) != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: all-reduce saw {int(ones.item())} ranks, WORLD_SIZE={world}")
+        RCCL_RANKS = int(ones.item()) if backend == "nccl" else 0
+    else:
+        RCCL_RANKS = 1
 
     from fl_scaling_sc_ldpc_amd import engine as E
 
@@ -212,9 +229,25 @@ def main():
 
 
 REHEARSAL = None
+RCCL_RANKS = 1
+
+
+def spawn_ranks(n, argv):
+    """Start `n` ranks of this script under torch.distributed.run as a CHILD process (rendezvous on 127.0.0.1, a free
+    port), pass its stdout/stderr through and return its exit code.  The parent has not touched the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def emit(out):
+    out["rccl_ranks"] = RCCL_RANKS                  # ranks counted by a real all-reduce over RCCL (0: rehearsal backend)
     if REHEARSAL:
         out["config"]["rehearsal"] = REHEARSAL      # not a reportable line: ranks shared devices / no RCCL
     print(json.dumps(out), flush=True)
@@ -305,6 +338,8 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     E_edges = p.n * p.dv
     b_alg = 16 * E_edges + p.n // 8
     share = 8 * E_edges + p.n // 8                      # each kernel's half: one direction of both tables + the channel bits
+    # what one kernel really writes (sampler) or has to read (decoder) per trial: the tables as they lie in HBM
+    table_bytes = (d_adj[0][0].numel() * d_adj[0].element_size() + (d_cn[0][0].numel() * 2 if gen2 else 0) + 4 * p.nw)
     value = total_trials / dt
     dec_name = "full_bp_small_kernel" if gen2 else "full_bp_kernel" if a.flooding else "full_bp_fixpoint_kernel"
     samp_name = "sample_philox_v2_kernel" if gen2 else "sample_philox_kernel"
@@ -317,7 +352,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     roof = {"bound": "hbm", "kernel": dec_name, "achieved": ach_dec, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach_dec / HBM_PEAK_GBS, "traffic": tr_dec["hbm_bytes"] if tr_dec else None,
             "traffic_raw": tr_dec["hbm_bytes_raw"] if tr_dec else None,
-            "alg_bytes_per_trial": share, "trials_per_launch": B, "ms_per_launch": ms_bp,
+            "alg_bytes_per_trial": share, "table_bytes_per_trial": table_bytes, "trials_per_launch": B, "ms_per_launch": ms_bp,
             "note": "decoder share of B_alg = 8E + n/8 (reads both tables once + the channel bits); `traffic` counts 128 B "
                     "per L2 read request (tools/calib: one request per random 8- or 16-byte gather)",
             "step": {"achieved": step_ach, "frac": step_ach / HBM_PEAK_GBS, "alg_bytes_per_trial": b_alg,

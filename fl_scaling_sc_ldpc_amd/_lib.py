@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("SCLDPC_LIB_PATH") or os.path.join(HERE, "libscldpc_hi
 
 NCOUNTERS = 8
 NRUN = 9
+NPEELRUN = 8
+PEELRUN_NAMES = ("trials", "fuckups", "lost", "fuckups_exp", "lost_exp", "blocks_exp")     # SCLDPC_PR_*
 COUNTER_NAMES = ("num_erasures", "num_blocks_err", "num_erasures_exp", "num_blocks_err_exp",
                  "num_erasures_p1", "iterations", "status", "channel_erasures")
 RUN_NAMES = ("users_err", "frame_err", "frame_err_p1", "block_err", "users_err_exp", "frame_err_exp",
@@ -37,6 +39,7 @@ EXPORTS = (
     "scldpc_full_bp_cn16_supported", "scldpc_full_bp_fixpoint_device_cn16", "scldpc_full_bp_device_cn16",
     "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
     "scldpc_sw_bp_ring_supported", "scldpc_cn_sockets_device", "scldpc_sw_bp_ring_device",
+    "scldpc_accumulate_peel_device", "scldpc_clear_channel_range_device",
 )
 
 
@@ -129,6 +132,8 @@ def lib():
     L.scldpc_cn_sockets_device.argtypes = [pp, i32, vp, vp, vp]
     L.scldpc_sw_bp_ring_device.argtypes = [pp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.scldpc_accumulate_run_device.argtypes = [i32, vp, i64, vp, vp]
+    L.scldpc_accumulate_peel_device.argtypes = [i32, vp, i64, vp, vp]
+    L.scldpc_clear_channel_range_device.argtypes = [pp, i32, i32, i32, vp, vp]
     L.scldpc_full_bp_lds_bytes.argtypes = [pp]
     L.scldpc_full_bp_lds_bytes.restype = i64
     _lib = L

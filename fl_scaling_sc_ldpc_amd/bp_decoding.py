@@ -15,9 +15,14 @@ grid order.  With fewer points than ranks (or --shard frames) the frames of a po
 the ranks instead; the only exchange is then an all-gather of the per-trial counter rows (32 B per trial),
 so that the ordered stop rule `frame_err >= 1000` cuts at the same frame on every rank.
 
+`bp_traj` is a one-point program that the reference runs as an array of processes, one per INDEX (BPT:2095, file name
+BPT:2131-2134; NB cell 35:21): under torch.distributed rank r IS process INDEX + r — it decodes that replica's frames
+alone and writes that replica's file, so an N-rank job leaves the N files that N single runs leave.
+
 Two sampling modes:
-  * rng="philox" (default): codes and channels drawn on the device, counter-based, trial t of point s
-    keyed by (seed, s·2^40 + t) — any batch size / GPU count gives the same files.
+  * rng="philox" (default): codes and channels drawn on the device, counter-based, trial t of point s of
+    replica INDEX keyed by (seed, INDEX·2^52 + s·2^40 + t) — any batch size / GPU count gives the same files, and the
+    processes of an array job (same --seed, different INDEX) draw disjoint streams.
   * rng="glibc": the reference's own stream, srandom(seed) once and frames drawn back to back with
     perm_code carried over — reproduces a reference run bit for bit on an identical seed (the
     reference seeds from gettimeofday, BPF:2059-2062; pass --seed to pin it).  Sampling is then a
@@ -36,7 +41,15 @@ import torch
 from . import engine as E
 from .engine import CodeParams, NCOUNTERS, NRUN, RUN_NAMES  # noqa: F401
 
-POINT_STRIDE = 1 << 40          # philox trial index = point * POINT_STRIDE + frame
+POINT_STRIDE = 1 << 40          # philox trial index = replica * REPLICA_STRIDE + point * POINT_STRIDE + frame
+REPLICA_STRIDE = 1 << 52        # replica = the executable's INDEX argument (one process of the reference's array jobs)
+
+
+def trial_key(index, sim, frame=0):
+    """Philox trial index of frame `frame` of ε point `sim` in the run of replica `index`."""
+    if not (0 <= index < 4096 and 0 <= sim < 4096 and 0 <= frame < POINT_STRIDE):
+        raise ValueError("INDEX and the point number must lie in [0, 4096)")
+    return index * REPLICA_STRIDE + sim * POINT_STRIDE + frame
 
 
 class GridSpec:
@@ -69,10 +82,11 @@ def _dist():
 class PointResult:
     """Counters of one ε point after the stop rule, as `risultati` needs them (BPF:499-515)."""
 
-    def __init__(self, eps, n, L, run):
+    def __init__(self, eps, n, L, run, bad=False):
         self.eps, self.n, self.L = eps, n, L
         self.run = {k: int(v) for k, v in zip(RUN_NAMES, run)}
         self.f = self.run["frames"]
+        self.bad = bool(bad)            # a frame broke decodeBP's invariant (BPF:1035-1039): the reference aborts there
 
     def row(self):
         r, f, n, L = self.run, self.f, self.n, self.L
@@ -114,17 +128,22 @@ class Simulator:
     """Batched Monte-Carlo driver around the device decoders."""
 
     def __init__(self, p, decoder="full", W=0, max_it=0, init_it=0, is_term=True, doped=(), batch=2048,
-                 rng="philox", seed=1, device=None, rows_cap=0, schedule="flooding", shard_frames=True):
+                 rng="philox", seed=1, device=None, rows_cap=0, schedule="flooding", shard_frames=True, index=0,
+                 verbose=False):
         self.p, self.decoder, self.W, self.max_it, self.init_it = p, decoder, W, max_it, init_it
+        self.index = index              # replica (the executables' INDEX): part of the Philox key
         self.schedule = schedule        # "fixpoint": unlimited full BP without the iteration count (1.2x faster)
         self.is_term, self.doped, self.batch, self.rng, self.seed = is_term, tuple(doped), batch, rng, seed
-        self.rows_cap = rows_cap
+        self.rows_cap, self.verbose = rows_cap, verbose
         self.dist, self.rank, self.world = _dist()
-        if not shard_frames:                    # ε points are sharded by the caller: every point runs on one rank
+        job_world = self.world
+        if not shard_frames:                    # ε points / replicas are sharded by the caller: every point runs on one rank
             self.dist, self.rank, self.world = None, 0, 1
         self.device = torch.device(device) if device is not None else E.local_device()
         if rng == "glibc":
-            if self.world != 1:
+            # checked on the JOB's world size: with the points sharded every rank would otherwise replay the same
+            # srandom(seed) stream from its start, where the reference carries random() and perm_code from point to point
+            if job_world != 1:
                 raise ValueError("rng='glibc' replays one sequential reference stream: single rank only")
             self.glibc = E.GlibcRun(p, seed)
         elif rng != "philox":
@@ -150,6 +169,23 @@ class Simulator:
                       and E.sock16_supported(p) and E.sw_ring_supported(p, self.W))
         self.d_cn = (torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device)
                      if (self.gen2 or self.lvl2 or self.ring2) else None)
+        if self.verbose:
+            print("[scldpc] kernels: " + self.kernel_choice(), file=sys.stderr, flush=True)
+
+    def kernel_choice(self):
+        """Which device kernels this configuration runs (the second-generation ones take dv = 4, dc = 8, N <= 2048)."""
+        if self.decoder == "sw":
+            return ("sampler_v2 (CN->socket table) + sw_ring (window state in LDS)" if self.ring2 else
+                    "sampler (first generation) + " + ("sw_ring + cn_sockets pass" if E.sw_ring_supported(self.p, self.W)
+                                                       and self.d_adj.dtype == torch.int16 else "sw_bp (whole chain)"))
+        samp = "glibc replay on the host" if self.rng == "glibc" else "sampler_v2 (CN->VN table)" if (self.gen2 or self.lvl2) \
+            else "sampler (first generation)"
+        if self.gen2:
+            return samp + " + full_bp_small fixpoint (4-bit CN counts)"
+        if self.lvl2:
+            return samp + " + full_bp_small level-synchronous (4-bit CN counts" + (", trajectory rows)" if self.rows_cap else ")")
+        return samp + " + full_bp (16-bit CN words" + (", trajectory rows)" if self.rows_cap else ")") + \
+            ": the second-generation decoder takes dv = 4, dc = 8, N <= 2048 with device sampling"
 
     def _accumulate(self, allcnt, run, stop_frame_err):
         return E.accumulate_run(allcnt, run, stop_frame_err)
@@ -174,13 +210,13 @@ class Simulator:
 
     def fill_batch(self, sim, eps, frame0, nb):
         if self.rng == "philox" and (self.gen2 or self.lvl2):
-            E.sample_philox_cn16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+            E.sample_philox_cn16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
                                  out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox" and self.ring2:
-            E.sample_philox_sock16(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+            E.sample_philox_sock16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
                                    out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox":
-            E.sample_philox(self.p, self.seed, sim * POINT_STRIDE + frame0, nb, eps, self.doped,
+            E.sample_philox(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
                             out=(self.d_adj[:nb], self.d_ch[:nb]))
         else:
             adj, ch = self.glibc.next_frames(nb, eps, self.doped)
@@ -199,13 +235,16 @@ class Simulator:
         offs = [sum(sizes[:r]) for r in range(world)]
         return R, sizes, offs
 
-    def run_point(self, sim, eps, min_frame_err, max_frames, on_batch=None):
+    def run_point(self, sim, eps, min_frame_err, max_frames, on_batch=None, defer_abort=False):
         """Frames 0,1,2,… of the point until frame_err >= min_frame_err or max_frames frames, in frame
         order (BPF:2117-2144).  Every round takes the next min(frames left, world·batch) frames and splits them
         evenly over the ranks; the per-trial counter rows are all-gathered and accumulated in frame order on
         every rank, so all ranks cut at the same frame.  The host looks at the run counters only in rounds in
         which the stop rule could trip (frames so far + this round >= min_frame_err); other rounds stay
-        asynchronous.  on_batch(frame0, frames_used, result) sees this rank's batches."""
+        asynchronous.  on_batch(frame0, frames_used, result) sees this rank's batches.
+        A frame that breaks decodeBP's invariant aborts the process as in the reference (BPF:1035-1039) — every rank of a
+        frame-sharded job sees it in the gathered rows and leaves together; with defer_abort the point comes back with
+        .bad set instead, for callers whose other ranks are busy elsewhere and must be told first."""
         p, B, W = self.p, self.batch, self.world
         i_frames, i_ferr, i_status = RUN_NAMES.index("frames"), RUN_NAMES.index("frame_err"), \
             E.COUNTER_NAMES.index("status")
@@ -251,11 +290,15 @@ class Simulator:
             frame0 += R
             if stopped:
                 break
-        if bool(bad):
-            # the reference aborts the process at such a frame (BPF:1035-1039)
-            print("ARGH! RECOVERED MORE VNs THAN deg-1 CNs! Aborting!")
-            raise SystemExit(-1)
-        return PointResult(eps, p.n, p.L, run.cpu().numpy())
+        if bool(bad) and not defer_abort:
+            abort_invariant()
+        return PointResult(eps, p.n, p.L, run.cpu().numpy(), bad=bool(bad))
+
+
+def abort_invariant():
+    """The reference aborts the process at a frame that recovers more VNs than it had degree-1 CNs (BPF:1035-1039)."""
+    print("ARGH! RECOVERED MORE VNs THAN deg-1 CNs! Aborting!", flush=True)
+    raise SystemExit(-1)
 
 
 def _write_traj_rows(fh, rows, counters, nb, cols=4):
@@ -304,18 +347,27 @@ def run_program(prog, index, W, num_doped, max_it, extra, opts):
     elif prog == "bp_traj":
         is_term = bool(extra)
     dist, rank, world = _dist()
-    # Sharding (module docstring): ε points over the ranks when there are at least as many points as ranks
-    # (the reference's own cluster model), else the frames of every point.
+    if opts.rng == "glibc" and world > 1:
+        # one srandom(seed) stream carried from frame to frame and from point to point (BPF:2057-2131): there is nothing to
+        # shard, and ranks replaying it from its start would write correlated points that look like a reference replay
+        raise SystemExit("--rng glibc replays the reference's one sequential random() stream: run it as a single process "
+                         "(%d ranks here); use --rng philox for multi-GPU jobs" % world)
+    # Sharding (module docstring): bp_traj — one replica (INDEX + rank) per rank; else ε points over the ranks when there
+    # are at least as many points as ranks (the reference's own cluster model), else the frames of every point.
     shard = getattr(opts, "shard", "auto")
-    if shard == "auto":
-        shard = "points" if (world > 1 and grid.num_points >= world and prog != "bp_traj") else "frames"
+    if prog == "bp_traj":
+        shard = "replicas"
+    elif shard == "auto":
+        shard = "points" if (world > 1 and grid.num_points >= world) else "frames"
     by_points = shard == "points" and world > 1
+    replica = index + rank if shard == "replicas" else index
     # the decoders' loop is do { … } while (iter < MaxNumIt) (BPF:1065, BPT:1076): at least one iteration runs
     cap = max(1, max_it)
     sim_obj = Simulator(p, decoder=decoder, W=W, max_it=cap, init_it=init_it,
                         is_term=is_term, doped=doped, batch=opts.batch, rng=opts.rng, seed=opts.seed,
                         rows_cap=opts.rows_cap if prog == "bp_traj" else 0, schedule=getattr(opts, "schedule", "flooding"),
-                        shard_frames=not by_points, device=getattr(opts, "device", None))
+                        shard_frames=shard == "frames", device=getattr(opts, "device", None), index=replica,
+                        verbose=rank == 0 and not opts.quiet)
     outdir = opts.outdir
     os.makedirs(outdir, exist_ok=True)
     t0 = time.time()
@@ -328,41 +380,60 @@ def run_program(prog, index, W, num_doped, max_it, extra, opts):
                   flush=True)
 
     if by_points:
-        # wave k = points [k·world, (k+1)·world): rank r runs point k·world + r alone, then one all-reduce of the
-        # run counters (NRUN int64 per point) hands the wave to rank 0, which appends the rows in grid order —
-        # finished waves survive a killed job like the reference's per-point fopen("a") (BPF:494-497).
+        # Rank r runs points r, r + world, r + 2·world, … back to back — no barrier between points, so a rank whose points
+        # stop early (frame_err >= 1000 long before max_frames) is not held up by the others.  Every finished point is
+        # appended to the rank's own part file at once (what a killed job leaves behind, like the reference's per-point
+        # fopen("a"), BPF:494-497); ONE all-reduce of the table [points][NRUN counters + abort flag] at the end hands the
+        # rows to rank 0, which writes the file in grid order and removes the parts.  A point that breaks decodeBP's
+        # invariant (BPF:1035-1039) only raises the flag: every rank reaches the all-reduce and all leave together.
         path = os.path.join(outdir, result_filename(prog, p, W, max_it, init_it, index))
-        for sim0 in range(0, grid.num_points, world):
-            wave = torch.zeros((world, NRUN), dtype=torch.int64, device=sim_obj.device)
-            sim = sim0 + rank
-            if sim < grid.num_points:
-                point = sim_obj.run_point(sim, grid.eps(sim), grid.min_frame_err, grid.max_frames)
-                wave[rank] = torch.tensor([point.run[k] for k in RUN_NAMES], dtype=torch.int64, device=sim_obj.device)
-            dist.all_reduce(wave)
-            if rank == 0:
-                rows = wave.cpu().numpy()
-                for r in range(min(world, grid.num_points - sim0)):
-                    pt = PointResult(grid.eps(sim0 + r), p.n, p.L, rows[r])
-                    write_risultati(path, sim0 + r, pt)
-                    report(pt.eps, pt)
+        part = path + ".rank%d.part" % rank
+        table = torch.zeros((grid.num_points, NRUN + 1), dtype=torch.int64, device=sim_obj.device)
+        for sim in range(rank, grid.num_points, world):
+            point = sim_obj.run_point(sim, grid.eps(sim), grid.min_frame_err, grid.max_frames, defer_abort=True)
+            table[sim, :NRUN] = torch.tensor([point.run[k] for k in RUN_NAMES], dtype=torch.int64, device=sim_obj.device)
+            table[sim, NRUN] = int(point.bad)
+            with open(part, "a" if sim != rank else "w") as f:
+                f.write("%d %s" % (sim, point.row()))
+            if point.bad:
+                break                                   # the reference's process is gone at this point
+        dist.all_reduce(table)
+        rows = table.cpu().numpy()
+        first_bad = next((s for s in range(grid.num_points) if rows[s, NRUN]), None)
+        if rank == 0:
+            for sim in range(grid.num_points if first_bad is None else first_bad):
+                pt = PointResult(grid.eps(sim), p.n, p.L, rows[sim, :NRUN])
+                if pt.f == 0:
+                    break                               # a rank stopped at an abort before reaching this point
+                write_risultati(path, sim, pt)
+                report(pt.eps, pt)
+        dist.barrier()
+        if os.path.exists(part):
+            os.remove(part)
+        if first_bad is not None:
+            abort_invariant()
         return 0
 
     for sim in range(grid.num_points):
         eps = grid.eps(sim)
         if prog == "bp_traj":
-            # one file per point and per rank-local batch order; bp_traj is a 1-point, ≤500-frame program
-            # (BPT:61-65): run it on one rank so the file keeps frame order.
-            if world != 1:
-                raise SystemExit("bp_traj writes frames in order: run it on a single rank")
-            path = os.path.join(outdir, traj_filename(p, eps, max_it, is_term, index))
+            # one file per ε point and per replica; this rank's replica writes its frames in order
+            path = os.path.join(outdir, traj_filename(p, eps, max_it, is_term, replica))
             with open(path, "w") as fh:
                 def on_batch(frame0, used, res):
                     _write_traj_rows(fh, res["rows"], res["counters"], used, cols=getattr(opts, "cols", 4))
-                point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames, on_batch=on_batch)
+                point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames, on_batch=on_batch,
+                                          defer_abort=world > 1)
         else:
             point = sim_obj.run_point(sim, eps, grid.min_frame_err, grid.max_frames)
             if rank == 0:
                 write_risultati(os.path.join(outdir, result_filename(prog, p, W, max_it, init_it, index)), sim, point)
+        if prog == "bp_traj" and world > 1:
+            # the replicas run independently; an abort in one of them (BPF:1035-1039) ends the job for all, together
+            flag = torch.tensor([int(point.bad)], dtype=torch.int64, device=sim_obj.device)
+            dist.all_reduce(flag)
+            if int(flag.item()):
+                abort_invariant()
         report(eps, point)
     return 0
 

@@ -1,6 +1,10 @@
 // Error reporting, parameter checks and small queries of libscldpc_hip.so.
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace scldpc {
 
@@ -28,6 +32,40 @@ int check_params(const scldpc_code_params *p)
     if ((int64_t)p->vns_pos * p->L > (1ll << 30) || (int64_t)(p->L + p->dv - 1) * p->cns_pos > (1ll << 30))
         return set_error(SCLDPC_ERR_TOO_LARGE, "ensemble too large for 32-bit node ids");
     return SCLDPC_OK;
+}
+
+int allow_max_lds(const void *kernel)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;      // (kernel, device): the attribute is kept per device
+    int dev = 0;
+    SCLDPC_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &kd : done)
+        if (kd.first == kernel && kd.second == dev) return SCLDPC_OK;
+    SCLDPC_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+    done.emplace_back(kernel, dev);
+    return SCLDPC_OK;
+}
+
+size_t debug_lds_pad(const char *which)
+{
+    char name[64];
+    snprintf(name, sizeof name, "SCLDPC_DEBUG_LDS_PAD_%s", which);
+    const char *v = getenv(name);
+    if (!v) return 0;
+    const long x = strtol(v, nullptr, 10);
+    return x > 0 && x < kMaxLdsBytes ? ((size_t)x + 15) & ~(size_t)15 : 0;
+}
+
+int debug_grid(const char *which, int ntrials)
+{
+    char name[64];
+    snprintf(name, sizeof name, "SCLDPC_DEBUG_GRID_%s", which);
+    const char *v = getenv(name);
+    if (!v) return ntrials;
+    const long x = strtol(v, nullptr, 10);
+    return x > 0 && x < ntrials ? (int)x : ntrials;
 }
 
 int take_scratch(const char *who, const Scratch &s, size_t need, void **out)

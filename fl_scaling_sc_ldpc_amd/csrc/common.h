@@ -40,6 +40,18 @@ inline bool magic_of(int d, int64_t limit, uint32_t *magic)
 
 constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgroup may take all of it
 
+// Lifts a kernel's dynamic-LDS limit to the CU's 160 KiB, ONCE per kernel and process, under a lock.  The attribute lives on
+// the process-global function object: set per call to the launch's own size, two host threads launching the same kernel for
+// different ensembles could lower it between the other thread's set and its launch.  0 or SCLDPC_ERR_HIP.
+int allow_max_lds(const void *kernel);
+
+// Diagnostics only (tools/ab_occupancy.py): extra bytes of dynamic LDS per workgroup from the environment variable
+// SCLDPC_DEBUG_LDS_PAD_<which>, to measure a kernel at fewer workgroups per CU than its own footprint allows.  0 if unset.
+size_t debug_lds_pad(const char *which);
+// Diagnostics only: SCLDPC_DEBUG_GRID_<which> = number of workgroups of a persistent launch (each loops over its trials);
+// unset or out of range: one workgroup per trial.
+int debug_grid(const char *which, int ntrials);
+
 #define SCLDPC_HIP_CHECK(expr)                                                                     \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

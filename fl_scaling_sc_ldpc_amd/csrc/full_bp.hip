@@ -549,8 +549,7 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     else kern = PICK(Wide, false, 1024);
 #undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(block), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
@@ -609,8 +608,7 @@ static int launch_full_bp_fixpoint(const scldpc_code_params *p, int32_t ntrials,
     a.vn_adj = d_vn_adj; a.chan = d_chan_bits; a.counters = d_counters; a.erased_out = d_erased_bits;
     void (*kern)(const Args) = adj16 ? full_bp_fixpoint_kernel<true, 1024> : full_bp_fixpoint_kernel<false, 1024>;
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(1024), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

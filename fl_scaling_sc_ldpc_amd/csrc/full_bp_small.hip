@@ -27,6 +27,7 @@
 // expurgated count (is_first_printed, BPF:1074, 1126-1132), so only that position's erased VNs are examined.
 #include "common.h"
 #include "kernel_util.h"
+#include <algorithm>
 
 namespace {
 
@@ -39,6 +40,7 @@ enum { LV_VALID = 2, LV_PUSH = 6, LV_DROP = 9, LV_REM = 12, LV_OVF = 15, LV_N = 
 struct SmArgs {
     int L, V, C, n, nk, cn_lim, nw, ncw;            // ncw = words of 8 count nibbles
     uint32_t magic_v, magic_c;
+    int ntrials;                                    // workgroup b decodes trials b, b + gridDim.x, …
     int kswitch;                                    // frontier width below which the waves go private
     int max_it;                                     // LEVEL: MaxNumIt, <= 0 = unlimited
     int off_U, off_q0, off_q1, off_pos, off_scal, off_fb, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
@@ -50,8 +52,8 @@ struct SmArgs {
 };
 
 // Seven 4-wave workgroups per CU are 7 waves per SIMD: at most 96 SGPRs and 72 VGPRs per wave (MI355X_MICROARCH.md).
-template <int BLOCK, bool LEVEL>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
+template <int BLOCK, bool LEVEL, bool PERSIST>
+__global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
 {
     constexpr int kWaves = BLOCK / 64;
     extern __shared__ uint32_t lds[];
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
     int *scal = reinterpret_cast<int *>(lds + a.off_scal);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int trial = blockIdx.x;
+    auto decode_trial = [&](const int trial) {
     const int n = a.n, nk = a.nk, cn_lim = a.cn_lim, nw = a.nw, V = a.V, C = a.C, L = a.L, qcap = a.qcap;
     const uint2 *vrow = reinterpret_cast<const uint2 *>(a.vn_adj16) + (size_t)trial * n;
     const uint4 *crow = reinterpret_cast<const uint4 *>(a.cn_adj16) + (size_t)trial * nk;
@@ -422,6 +424,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96))) void fu
         o[SCLDPC_C_STATUS] = status;
         o[SCLDPC_C_CHANNEL_ERASURES] = nch;
     }
+    };
+    // PERSIST: workgroup b decodes trials b, b + gridDim.x, …; otherwise exactly one
+    if constexpr (PERSIST) {
+        for (int trial = blockIdx.x; trial < a.ntrials; trial += gridDim.x) {
+            decode_trial(trial);
+            __syncthreads();                                             // LDS is re-used by the workgroup's next trial
+        }
+    } else {
+        decode_trial((int)blockIdx.x);
+    }
 }
 
 int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_cu, bool level = false)
@@ -487,12 +499,15 @@ int launch_small(const char *who, bool level, const scldpc_code_params *p, int32
     a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
     a.counters = d_counters; a.erased_out = d_erased_bits;
     a.kswitch = kSwitchWidth;
+    a.ntrials = ntrials;
     a.max_it = max_it;
-    void (*kern)(const SmArgs) = level ? full_bp_small_kernel<kBlockSmall, true> : full_bp_small_kernel<kBlockSmall, false>;
-    const size_t lds_bytes = 4u * (size_t)a.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlockSmall), lds_bytes, static_cast<hipStream_t>(stream), a);
+    const int grid = scldpc::debug_grid("DECODER", ntrials);
+    void (*kern)(const SmArgs) = grid < ntrials ? (level ? full_bp_small_kernel<kBlockSmall, true, true> : full_bp_small_kernel<kBlockSmall, false, true>)
+                                                : (level ? full_bp_small_kernel<kBlockSmall, true, false> : full_bp_small_kernel<kBlockSmall, false, false>);
+    size_t lds_bytes = 4u * (size_t)a.total;
+    lds_bytes = std::min(lds_bytes + scldpc::debug_lds_pad("DECODER"), (size_t)scldpc::kMaxLdsBytes);
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlockSmall), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
 }

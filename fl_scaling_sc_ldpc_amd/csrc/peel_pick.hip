@@ -303,8 +303,7 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
                                : (adj16 ? peel_pick_kernel<0, true, G, D> : peel_pick_kernel<0, false, G, D>))
     kern = d1g ? PICK(true, true) : gws ? PICK(true, false) : PICK(false, false);
 #undef PICK
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

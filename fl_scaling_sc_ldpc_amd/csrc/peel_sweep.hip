@@ -307,8 +307,7 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
     kern = mode == 0 ? PICK(Packed) : mode == 1 ? PICK(Wide) : PICK(WideG);
 #undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

@@ -551,8 +551,7 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         if (int rc = scldpc::take_scratch(who, scratch, stride * (size_t)ntrials, &ws)) return rc;
         void (*kb)(const SArgs, char *, size_t) = a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16>
                                                                  : sample_philox_big_kernel<8, ADJ16>;
-        SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kb))) return rc_;
         hipLaunchKernelGGL(kb, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a,
                            static_cast<char *>(ws), stride);
         SCLDPC_HIP_CHECK(hipGetLastError());
@@ -574,8 +573,7 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         else           kern = sample_philox_kernel<2, 8, ADJ16, 0, true>;
         if (kmax == 1 && rows > 4) kern = sample_philox_kernel<2, 8, ADJ16, 0, true>;
     }
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

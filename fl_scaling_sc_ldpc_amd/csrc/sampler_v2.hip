@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernel_util.h"
 #include "philox.h"
+#include <algorithm>
 
 namespace {
 
@@ -30,6 +31,7 @@ constexpr int kWorkCap = 1024;          // keys of buckets that span two CNs, pe
 
 struct S2Args {
     int L, cns_pos, vns_pos, n, S, D, nb, shift, sbits, nw;
+    int ntrials;                        // workgroup b samples trials b, b + gridDim.x, … (gridDim.x == ntrials unless persistent)
     int ndoped;
     int doped[kMaxDoped];
     uint32_t seed_lo, seed_hi;
@@ -45,8 +47,8 @@ struct S2Args {
 // ROWS = histogram words per thread (nb / 1024)
 // CNMODE: what the rank-ordered stage holds — 0 nothing, 1 the sockets' VNs (global VN index, scldpc_sample_philox_device_cn16),
 //         2 the sockets themselves (s = dv*t + i: the table scldpc_sw_bp_ring_device reads; any n)
-template <int KMAX, int ROWS, int CNMODE>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_v2_kernel(const S2Args a)
+template <int KMAX, int ROWS, int CNMODE, bool PERSIST = false>
+__global__ __launch_bounds__(kThreads, KMAX == 1 ? 8 : 4) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_v2_kernel(const S2Args a)
 {
     constexpr int DV = 4, DC_SHIFT = 3, E = 4 * KMAX;
     extern __shared__ uint32_t lds[];
@@ -58,8 +60,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     uint32_t *wl = wsum + 32;                                           // worklist: 2 words per key of a straddling bucket
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long trial = a.trial0 + blockIdx.x;
-    const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     const int S = a.S, nb = a.nb;
     const int ncalls = S >> 2;                                          // S % 4 == 0 (checked on the host)
     const int kshift = a.shift - 2;                                     // key >> kshift = fine bucket
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     for (int b = tid; b < nb; b += kThreads) hist[b] = 0;
     if (tid == 0) wsum[kWaves] = 0;
     __syncthreads();
+    auto sample_trial = [&](const int tr) {
+    const unsigned long long trial = a.trial0 + (unsigned long long)tr;
+    const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     // The keys of position p+1 are drawn (pure VALU) while the few worklist lanes of position p chase their bucket mates
     // through the LDS: nxt[] carries them across the barrier.
     // Thread t draws the keys of sockets 4t .. 4t+3 of every CN position, and socket 4t+i of CN position q+i is edge i of
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
             uint2 c = make_uint2(0u, 0u);                               // [edge 0 | edge 1], [edge 2 | edge 3] of this step
             if (own[k]) c = reinterpret_cast<const uint2 *>(fix)[tid + k * kThreads];
             if (qpos >= 0 && own[k]) {
-                const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + (size_t)(tid + k * kThreads);
+                const size_t j = (size_t)tr * a.n + (size_t)qpos * a.vns_pos + (size_t)(tid + k * kThreads);
                 uint2 v;
                 v.x = rowP[k];
                 v.y = (rowR[k] >> 16) | (c.y & 0xFFFF0000u);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
             rowR[k] = (c.x & 0xFFFFu) | (c.y << 16);
         }
         if constexpr (CNMODE != 0) {
-            uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)blockIdx.x * a.D + p) * (size_t)(S >> 2);
+            uint2 *dst = reinterpret_cast<uint2 *>(a.cn_adj16) + ((size_t)tr * a.D + p) * (size_t)(S >> 2);
             const uint2 *src = reinterpret_cast<const uint2 *>(stage);
             for (int w = tid; w < (S >> 2); w += kThreads) dst[w] = src[w];
         }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
     }
 
     // ---- channel: 32 VNs per output word, 8 Philox calls
-    uint32_t *chan = a.chan + (size_t)blockIdx.x * a.nw;
+    uint32_t *chan = a.chan + (size_t)tr * a.nw;
     for (int w = tid; w < a.nw; w += kThreads) {
         uint32_t word = 0;
 #pragma unroll
@@ -299,6 +302,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
         chan[w] = word;
     }
     STAMP(6);
+    };
+    // PERSIST (diagnostics): workgroup b samples trials b, b + gridDim.x, …; otherwise exactly one
+    if constexpr (PERSIST) {
+        for (int tr = blockIdx.x; tr < a.ntrials; tr += gridDim.x) {
+            sample_trial(tr);
+            __syncthreads();                            // the stage of the last position has been copied out
+        }
+    } else {
+        sample_trial((int)blockIdx.x);
+    }
     STAMP_FLUSH();
 }
 
@@ -340,10 +353,12 @@ int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t
     a.off_fix = off;   off += (a.S / 2 + 3) & ~3;           // S uint16
     a.off_stage = off; off += cnmode ? (a.S / 2 + 3) & ~3 : 0;
     a.off_wsum = off;  off += 32 + 2 * kWorkCap;
-    const size_t lds_bytes = 4u * (size_t)off;
+    size_t lds_bytes = 4u * (size_t)off;
+    lds_bytes = std::min(lds_bytes + scldpc::debug_lds_pad("SAMPLER"), std::max(lds_bytes, (size_t)scldpc::kMaxLdsBytes));
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: %zu bytes of LDS per trial", who, lds_bytes);
     a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_table; a.chan = d_chan_bits;
+    a.ntrials = ntrials;
 
     using Kern = void (*)(const S2Args);
     static const Kern table[4][3] = {
@@ -353,10 +368,12 @@ int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t
         {sample_philox_v2_kernel<2, 8, 0>, sample_philox_v2_kernel<2, 8, 1>, sample_philox_v2_kernel<2, 8, 2>},
     };
     const int rows = a.nb / kThreads;                       // 1, 2, 4 (one Philox call per thread) or 8 (two)
-    const Kern kern = table[rows == 1 ? 0 : rows == 2 ? 1 : rows == 4 ? 2 : 3][cnmode];
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
+    const int grid = scldpc::debug_grid("SAMPLER", ntrials);
+    Kern kern = table[rows == 1 ? 0 : rows == 2 ? 1 : rows == 4 ? 2 : 3][cnmode];
+    if (grid < ntrials && rows == 4 && cnmode == 1) kern = sample_philox_v2_kernel<1, 4, 1, true>;     // diagnostics: persistent launch
+    else if (grid < ntrials) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "SCLDPC_DEBUG_GRID_SAMPLER: only the <1,4,1> kernel has a persistent form");
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
 }

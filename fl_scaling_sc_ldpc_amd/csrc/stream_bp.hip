@@ -529,8 +529,7 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_bytes);
     void (*kern)(const Args) = rows == 1 ? stream_bp_kernel<1> : rows == 2 ? stream_bp_kernel<2>
                                : rows == 4 ? stream_bp_kernel<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

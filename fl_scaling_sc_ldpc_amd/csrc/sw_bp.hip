@@ -313,8 +313,7 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
     kern = packed ? PICK(Packed) : gws ? PICK(WideG) : PICK(Wide);
 #undef PICK
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

@@ -434,8 +434,7 @@ extern "C" int scldpc_cn_sockets_device(const scldpc_code_params *p, int32_t ntr
     const long long blocks = (long long)ntrials * (p->L + p->dv - 1);
     if (blocks > 0x7FFFFFFFll)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_cn_sockets_device: too many (trial, position) pairs for one launch");
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cn_sockets_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(cn_sockets_kernel))) return rc_;
     hipLaunchKernelGGL(cn_sockets_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
@@ -461,8 +460,7 @@ extern "C" int scldpc_sw_bp_ring_device(const scldpc_code_params *p, int32_t ntr
     a.counters = d_counters; a.erased_out = d_erased_bits;
     void (*kern)(const RArgs) = sw_ring_kernel<4, 8>;
     const size_t lds_bytes = 4u * (size_t)a.total;
-    SCLDPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;

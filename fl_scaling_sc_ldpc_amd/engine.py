@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CodeParams, NCOUNTERS, NRUN, COUNTER_NAMES, RUN_NAMES, ScldpcError, check, lib  # noqa: F401
+from ._lib import (CodeParams, NCOUNTERS, NRUN, NPEELRUN, COUNTER_NAMES, RUN_NAMES, PEELRUN_NAMES, ScldpcError,  # noqa: F401
+                   check, lib)
 
 
 def make_params(dv=4, dc=8, L=50, N=1000):
@@ -396,6 +397,21 @@ def accumulate_run(d_counters, d_run, stop_frame_err=0):
     check(lib().scldpc_accumulate_run_device(d_counters.shape[0], d_counters.data_ptr(), int(stop_frame_err),
                                              d_run.data_ptr(), _stream_ptr(d_counters.device)))
     return d_run
+
+
+def accumulate_peel(d_out, d_run, max_fuckups=0):
+    """simulate_sc_ldpc's ordered bookkeeping + stop rule (PD:668-699) over a batch of peel_sweep rows; d_run int64
+    [NPEELRUN] (order of _lib.PEELRUN_NAMES) accumulated in place."""
+    check(lib().scldpc_accumulate_peel_device(d_out.shape[0], d_out.data_ptr(), int(max_fuckups), d_run.data_ptr(),
+                                              _stream_ptr(d_out.device)))
+    return d_run
+
+
+def clear_channel_range(p, d_ch, vn_lo, vn_hi):
+    """Soft doping (PD:176-183): VNs vn_lo .. vn_hi-1 of every trial become known."""
+    check(lib().scldpc_clear_channel_range_device(C.byref(p), d_ch.shape[0], int(vn_lo), int(vn_hi), d_ch.data_ptr(),
+                                                  _stream_ptr(d_ch.device)))
+    return d_ch
 
 
 def new_run(device="cuda:0"):

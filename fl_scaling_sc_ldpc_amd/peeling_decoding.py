@@ -114,6 +114,13 @@ def _dist():
     return None, 0, 1
 
 
+def _free_bytes(device):
+    """Free memory on `device` right now (the row buffers and batch sizes are budgeted against it, so that a smaller
+    part, or a GPU shared between ranks, is not driven out of memory)."""
+    dev = torch.device(device)
+    return torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else int(32e9)
+
+
 def _device(device):
     """Default device: this rank's GPU (LOCAL_RANK), as torch.distributed.run sets it."""
     return device if device is not None else str(E.local_device())
@@ -177,10 +184,13 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
     p = g.params
     if batch is None:
         batch = 64 if rng == "numpy" else 2048
-    num_fuckups = num_fuckups_truncated = 0
-    total_generated = total_failed = total_failed_expurgated = 0
-    total_blocks_generated = total_blocks_failed_exp = 0
+    # The reference's per-trial bookkeeping and its stop rule (PD:668-699) run on the device, in trial order
+    # (scldpc_accumulate_peel_device): the host reads the six totals only in rounds in which max_fuckups could trip.
+    run = torch.zeros(E.NPEELRUN, dtype=torch.int64, device=device)
+    i_tr, i_fu = E.PEELRUN_NAMES.index("trials"), E.PEELRUN_NAMES.index("fuckups")
     done = 0
+    fuckups_bound = 0                                   # upper bound on num_fuckups while nobody has looked
+    soft = isinstance(doping_points, dict)
     while done < num_repeats:
         nb = min(batch * world, num_repeats - done)         # trials of this round (all ranks)
         offs = _split(nb, world)
@@ -196,11 +206,14 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
                 states.append(np.random.get_state())
             d_adj, d_ch = E.to_device(adj, ch, device)
         elif rng == "philox":
-            if isinstance(doping_points, dict):
-                raise NotImplementedError("soft doping needs the host sampler (rng='numpy')")
+            if soft and is_protograph:
+                raise NameError("name 'position' is not defined")   # the reference's own failure for soft doping (PD:228)
             ens = "protograph" if is_protograph else "tail_biting" if is_tail_biting else "olmos"
-            d_adj, d_ch = E.sample_philox(p, seed, done + lo, mine, e, _doped_positions(doping_points), device=device,
-                                          adj16=(ens == "olmos"), ensemble=ens)
+            d_adj, d_ch = E.sample_philox(p, seed, done + lo, mine, e, [] if soft else _doped_positions(doping_points),
+                                          device=device, adj16=(ens == "olmos"), ensemble=ens)
+            if soft:                                        # PD:176-183: the first int(alpha*M) VNs of the position are known
+                for pos, alpha in doping_points.items():
+                    E.clear_channel_range(p, d_ch, pos * M, pos * M + int(alpha * M))
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
         d_out = E.peel_sweep(p, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"]
@@ -210,27 +223,25 @@ def simulate_sc_ldpc(e, l, r, L, M, is_terminated, is_protograph, is_bounded, is
             pad[:mine] = d_out
             parts = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(parts, pad)
-            d_out = torch.cat([parts[r][:offs[r + 1] - offs[r]] for r in range(world)], dim=0)
-        out = d_out.cpu().numpy()
-        # ordered accumulation with the reference's stop rule (PD:668-699)
-        used = nb
-        for t in range(nb):
-            lost, lost_exp, blocks_exp = int(out[t, 0]), int(out[t, 1]), int(out[t, 2])
-            total_generated += g.generated
-            total_blocks_generated += g.blocks
-            num_fuckups += lost >= 1
-            total_failed += lost
-            num_fuckups_truncated += lost_exp > 0
-            total_failed_expurgated += lost_exp
-            total_blocks_failed_exp += blocks_exp
-            if num_fuckups >= max_fuckups:
-                used = t + 1
-                break
+            d_out = torch.cat([parts[r][:offs[r + 1] - offs[r]] for r in range(world)], dim=0).contiguous()
+        E.accumulate_peel(d_out, run, max_fuckups)
+        fuckups_bound += nb
+        if fuckups_bound < max_fuckups and states is None:
+            done += nb                                      # cannot have tripped: stay asynchronous
+            continue
+        tot = run.cpu().numpy()
+        used = int(tot[i_tr]) - done
+        fuckups_bound = int(tot[i_fu])
         done += used
-        if used < nb or num_fuckups >= max_fuckups:
+        if used < nb or tot[i_fu] >= max_fuckups:
             if states is not None:
                 np.random.set_state(states[used - 1])       # leave the stream where the reference stops drawing
             break
+    tot = {k: int(v) for k, v in zip(E.PEELRUN_NAMES, run.cpu().numpy())}
+    assert tot["trials"] == done
+    num_fuckups, num_fuckups_truncated = tot["fuckups"], tot["fuckups_exp"]
+    total_failed, total_failed_expurgated, total_blocks_failed_exp = tot["lost"], tot["lost_exp"], tot["blocks_exp"]
+    total_generated, total_blocks_generated = done * g.generated, done * g.blocks
     o1 = done
     failures, gens = np.zeros(num_repeats), np.zeros(num_repeats)
     return (num_fuckups / o1, num_fuckups_truncated / o1, total_failed / total_generated,
@@ -288,8 +299,11 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
     moments = None
     if batch is None:
         # one wave steps one trial: the kernel wants ~8192 trials in flight; stay below ~16 GB of device buffers
-        per_trial = L * M * l_deg * 4 + (0 if want_moments else 4 * (num_pd_steps + 1))
-        batch = max(256, min(8192, int(16e9 // per_trial)))
+        # (tables + CN words + picks' scratch ~ 3 x the int32 adjacency; r1 rows 4 B per step where they are written)
+        rows_wanted = (not want_moments) or moments_from in ("auto", "rows")
+        per_trial = 3 * L * M * l_deg * 4 + (4 * (num_pd_steps + 1) if rows_wanted else 0)
+        free = _free_bytes(device)
+        batch = max(64, min(8192, int(min(16e9 + (24e9 if rows_wanted and want_moments else 0), 0.6 * free) // per_trial)))
     offs = _split(num_repeats, world)
     if want_moments:
         moments = torch.zeros((3, num_pd_steps + 1), dtype=torch.int64, device=device)
@@ -301,8 +315,10 @@ def simulate_peeling_decoder_ldpc(e, l_deg, r_deg, L, M, is_terminated, is_proto
         # (4 B per step and trial) they are written instead and reduced by one pass of r1_moments
         if moments_from not in ("auto", "rows", "kernel"):
             raise ValueError("moments_from must be 'auto', 'rows' or 'kernel'")
+        # "auto": rows where they fit a quarter of what is free on THIS device right now (shared / smaller parts included)
         rows_first = want_moments and (moments_from == "rows" or
-                                       (moments_from == "auto" and 4 * (num_pd_steps + 1) * nb <= 24e9))
+                                       (moments_from == "auto" and
+                                        4 * (num_pd_steps + 1) * nb <= min(24e9, 0.25 * _free_bytes(device))))
         res = E.peel_pick(p, d_adj, d_ch, total_size, num_pd_steps, mt_state=None, seed=seed, trial0=done,
                           want_r1=not want_moments or rows_first, moments=None if rows_first else moments)
         if rows_first:
@@ -445,10 +461,21 @@ def _cli_options(args, kw):
     return pos, kw
 
 
+def _join_job(kw):
+    """Under torch.distributed.run only the throughput mode shards: the reference's own streams (rng="numpy", the default)
+    are one sequential sequence, and ranks that each believed to be rank 0 would all write the same output file."""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and kw.get("rng") != "philox":
+        raise SystemExit("rng='numpy' replays the reference's one sequential numpy / random stream: run it as a single "
+                         "process, or pass --rng philox to shard the trials over the %s ranks of this job"
+                         % os.environ["WORLD_SIZE"])
+    return E.init_distributed() if kw.get("rng") == "philox" else False
+
+
 def main_simulate_sc_ldpc(argv=None, **kw):
     """ber_sim.py: OUT l r L M "es" T|N U|P B|N TB|NTB num_repeats max_fuckups "doping" (PD:1327-1356)."""
     a, kw = _cli_options(sys.argv if argv is None else [None] + list(argv), kw)
-    joined = E.init_distributed() if kw.get("rng") == "philox" else False
+    joined = _join_job(kw)
     try:
         return _main_simulate_sc_ldpc(a, kw)
     finally:
@@ -502,7 +529,7 @@ def main_simulate_variance(argv=None, **kw):
     """simulate_variance.py: OUT l r L M e T|N U|P num_runs num_runs_batch THEORY (PD:1264-1294): writes
     pickle.dump((ssquares, counts))."""
     a, kw = _cli_options(sys.argv if argv is None else [None] + list(argv), kw)
-    joined = E.init_distributed() if kw.get("rng") == "philox" else False
+    joined = _join_job(kw)
     try:
         return _main_simulate_variance(a, kw)
     finally:

@@ -342,6 +342,26 @@ int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int32_t nstream
 int scldpc_accumulate_run_device(int32_t ntrials, const int32_t *d_counters, int64_t stop_frame_err,
                                  int64_t *d_run, void *stream);
 
+/* simulate_sc_ldpc's bookkeeping over a batch, IN TRIAL ORDER, with its stop rule (PD:668-699): adds the rows of
+ * scldpc_peel_sweep_device (d_out int32 [ntrials][8]) of trials 0..k into d_run[SCLDPC_NPEELRUN] (int64, in place), k =
+ * the first trial at which the number of failed trials (`num_fuckups`, #lost >= 1) reaches max_fuckups (all trials if
+ * it never does or max_fuckups <= 0).  A run that has already reached it consumes nothing. */
+enum {
+    SCLDPC_PR_TRIALS = 0,       /* o + 1 of the reference's loop (PD:635, 700)      */
+    SCLDPC_PR_FUCKUPS = 1,      /* num_fuckups           (PD:668-670)                */
+    SCLDPC_PR_LOST = 2,         /* total_failed          (PD:671)                    */
+    SCLDPC_PR_FUCKUPS_EXP = 3,  /* num_fuckups_truncated (PD:691-693)                */
+    SCLDPC_PR_LOST_EXP = 4,     /* total_failed_expurgated (PD:680, 694)             */
+    SCLDPC_PR_BLOCKS_EXP = 5,   /* total_blocks_failed_exp (PD:684-689, 695)         */
+    SCLDPC_NPEELRUN = 8
+};
+int scldpc_accumulate_peel_device(int32_t ntrials, const int32_t *d_out, int64_t max_fuckups, int64_t *d_run, void *stream);
+
+/* Soft doping of the Python path (gen_users_sc_ldpc_doping, PD:176-183: `erasure[pos*M : pos*M + int(alpha*M)] = False`):
+ * clears the channel bits of VNs vn_lo .. vn_hi-1 of every trial in d_chan_bits [ntrials][ceil(n/32)]. */
+int scldpc_clear_channel_range_device(const scldpc_code_params *p, int32_t ntrials, int32_t vn_lo, int32_t vn_hi,
+                                      uint32_t *d_chan_bits, void *stream);
+
 /* LDS bytes the full-BP kernel needs for this ensemble (<= 163840 to be launchable), or a negative error. */
 int64_t scldpc_full_bp_lds_bytes(const scldpc_code_params *p);
 

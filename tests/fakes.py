@@ -47,14 +47,28 @@ class FakeSimulator(B.Simulator):
     def _alloc(self):
         self.d_cnt = torch.zeros((self.batch, E.NCOUNTERS), dtype=torch.int32)
 
+    bad_frames = ()                             # (sim, frame) pairs whose status word reports a broken invariant
+
     def fill_batch(self, sim, eps, frame0, nb):
         self._frames = (sim, np.arange(frame0, frame0 + nb))
         self.frames_decoded += nb
 
     def decode_batch(self, nb, want_rows=False):
         sim, idx = self._frames
-        self.d_cnt[:nb] = torch.from_numpy(fake_counters(sim, idx, self.p.n, self.p.L))
-        return {"counters": self.d_cnt[:nb], "rows": None, "erased": None}
+        key = sim + 1000 * self.index            # the replica (INDEX) is part of the trial key
+        cnt = fake_counters(key, idx, self.p.n, self.p.L)
+        for k, f in enumerate(idx):
+            if (sim, int(f)) in self.bad_frames:
+                cnt[k, E.COUNTER_NAMES.index("status")] = -1
+        self.d_cnt[:nb] = torch.from_numpy(cnt)
+        rows = None
+        if want_rows:                           # bp_traj: `iterations` rows of (deg1, recovered, first erased position)
+            rows = torch.zeros((nb, self.rows_cap, 3), dtype=torch.int32)
+            for k, f in enumerate(idx):
+                it = int(cnt[k, 5])
+                r = np.arange(it, dtype=np.int64)
+                rows[k, :it] = torch.from_numpy(np.stack([(r * 7 + f + key) % 97, (r * 3 + f) % 89, r % self.p.L], 1).astype(np.int32))
+        return {"counters": self.d_cnt[:nb], "rows": rows, "erased": None}
 
     def _new_run(self):
         return torch.zeros(E.NRUN, dtype=torch.int64)

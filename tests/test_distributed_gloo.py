@@ -107,6 +107,95 @@ def test_points_and_frames_sharding_write_the_single_rank_file(tmp_path):
     assert work[(2, "frames")] == {0: 2500, 1: 2500}            # 500 + 500 of every point's 1000 frames
 
 
+def _case_worker(rank, world, port, outdir, case, q):
+    """run_program under gloo with the device work faked; puts (rank, exit code or exception text) on q."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fakes
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    B.Simulator = fakes.FakeSimulator
+    prog, argv = case["prog"], list(case["argv"]) + ["--outdir", outdir, "--quiet", "--seed", "3"]
+    fakes.FakeSimulator.bad_frames = tuple(case.get("bad", ()))
+    opts = B._parser(prog).parse_args(argv)
+    extra = getattr(opts, "IS_TERM", None) if prog == "bp_traj" else None
+    try:
+        rc = B.run_program(prog, opts.INDEX, opts.W, opts.NUM_DOPED, opts.MAX_IT, extra, opts)
+    except SystemExit as e:
+        rc = e.code
+    q.put((rank, rc))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_case(tmp_path, tag, world, case, port):
+    ctx = mp.get_context("spawn")
+    d = str(tmp_path / tag)
+    os.makedirs(d, exist_ok=True)
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_case_worker, args=(r, world, port, d, case, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    rcs = dict(q.get(timeout=120) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    return d, rcs
+
+
+def test_glibc_replay_is_refused_on_more_than_one_rank(tmp_path):
+    """--rng glibc is ONE srandom stream carried from point to point (BPF:2057-2131): a multi-rank job would replay it from
+    its start on every rank.  run_program refuses before choosing a shard mode (points mode used to slip through)."""
+    case = {"prog": "bp_lim_iter", "argv": ["0", "0", "0", "50", "--L", "10", "--N", "10", "--num-points", "4", "--max-frames", "20",
+                                            "--rng", "glibc"]}
+    d, rcs = _run_case(tmp_path, "glibc2", 2, case, 34100 + os.getpid() % 1000)
+    assert all(isinstance(rc, str) and "single process" in rc for rc in rcs.values()), rcs
+    assert os.listdir(d) == []
+
+
+def test_points_mode_abort_leaves_together_and_keeps_the_rows_before(tmp_path):
+    """A frame that breaks decodeBP's invariant (status != 0, BPF:1035-1039) on ONE rank's point: the flag travels with the
+    counters, every rank exits -1 after the same all-reduce (none is left waiting in a collective), and the file holds
+    the rows of the points before the broken one, as the reference's per-point append would have left them."""
+    base = ["2", "0", "0", "50", "--L", "10", "--N", "10", "--num-points", "5", "--max-frames", "200", "--min-frame-err", "1000",
+            "--shard", "points"]
+    port = 34300 + os.getpid() % 1000
+    d_ok, rcs = _run_case(tmp_path, "ok", 2, {"prog": "bp_lim_iter", "argv": base}, port)
+    assert rcs == {0: 0, 1: 0}
+    d_bad, rcs = _run_case(tmp_path, "bad", 2, {"prog": "bp_lim_iter", "argv": base, "bad": [(3, 17)]}, port + 11)
+    assert rcs == {0: -1, 1: -1}, rcs                          # point 3 belongs to rank 1; rank 0 leaves with it
+    name = "SC_LDPC_4_8_L10_M5_BP_SW0_50it_Random_BLER_2.dat"
+    assert sorted(os.listdir(d_ok)) == [name] and sorted(os.listdir(d_bad)) == [name]      # part files removed
+    ok, bad = open(os.path.join(d_ok, name)).read().split("\n"), open(os.path.join(d_bad, name)).read().split("\n")
+    assert len(ok) == 7 and bad[:4] == ok[:4] and len(bad) == 5                          # header + points 0, 1, 2
+    # one rank: the abort is immediate, as in the reference
+    d_one, rcs = _run_case(tmp_path, "bad1", 1, {"prog": "bp_lim_iter", "argv": base, "bad": [(3, 17)]}, port + 22)
+    assert rcs == {0: -1}
+    assert open(os.path.join(d_one, name)).read().split("\n")[:4] == ok[:4]
+
+
+def test_bp_traj_ranks_are_the_replicas_of_an_array_job(tmp_path):
+    """bp_traj on two ranks = the processes INDEX and INDEX + 1 of the reference's array job (BPT:2095, 2131-2134;
+    NB cell 35:21): two files, each byte for byte what the single process with that INDEX writes."""
+    argv = ["0", "0", "1000000", "1", "--L", "10", "--N", "10", "--max-frames", "23", "--min-frame-err", "23", "--batch", "8"]
+    port = 34600 + os.getpid() % 1000
+    d2, rcs = _run_case(tmp_path, "two", 2, {"prog": "bp_traj", "argv": ["6"] + argv}, port)
+    assert rcs == {0: 0, 1: 0}
+    names = sorted(os.listdir(d2))
+    assert names == ["trajectories_0.4600_terminated_SC_LDPC_4_8_L10_M5_BP_Full_1000000it_Random_BLER_%d.dat" % i for i in (6, 7)]
+    texts = [open(os.path.join(d2, nm)).read() for nm in names]
+    assert texts[0] != texts[1]                                # different replicas draw different frames
+    for k, idx in enumerate(("6", "7")):
+        d1, rcs = _run_case(tmp_path, "one" + idx, 1, {"prog": "bp_traj", "argv": [idx] + argv}, port + 13 + k)
+        assert rcs == {0: 0} and os.listdir(d1) == [names[k]]
+        assert open(os.path.join(d1, names[k])).read() == texts[k]
+        assert len(texts[k].split("\n\n")) - 1 == 23         # 23 frames, an empty line after each
+
+
 def test_split_round_gives_every_rank_work_at_the_defaults():
     from fl_scaling_sc_ldpc_amd import bp_decoding as B
     R, sizes, offs = B.Simulator.split_round(1000, 2048, 8)
@@ -198,8 +287,17 @@ def _fake_engine(PD):
         moments[2] += (r * r).sum(0)
         return moments
 
+    def accumulate_peel(d_out, run, max_fuckups=0):        # literal loop of PD:668-699 over the rows, in trial order
+        r = run.numpy()
+        for row in d_out.numpy():
+            if max_fuckups > 0 and r[1] >= max_fuckups:
+                break
+            r[0] += 1; r[1] += row[0] >= 1; r[2] += row[0]; r[3] += row[1] > 0; r[4] += row[1]; r[5] += row[2]
+        return run
+
     PD.E = types.SimpleNamespace(sample_philox=sample_philox, peel_sweep=peel_sweep, peel_pick=peel_pick,
-                                 r1_moments=r1_moments, CodeParams=PD.E.CodeParams)
+                                 r1_moments=r1_moments, CodeParams=PD.E.CodeParams, accumulate_peel=accumulate_peel,
+                                 NPEELRUN=PD.E.NPEELRUN, PEELRUN_NAMES=PD.E.PEELRUN_NAMES)
 
 
 def _pd_worker(rank, world, port, q):

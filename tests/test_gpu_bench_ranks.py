@@ -35,6 +35,31 @@ def _bench(world, *args):
     return json.loads(lines[0])
 
 
+def test_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the driver's command form): the script starts the two ranks itself
+    and rank 0's single line says n_gpus 2, with the error counts of one rank over the same trial indices."""
+    require_gpu()
+    env = dict(os.environ, SCLDPC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--steps", "2",
+                        "--warmup", "1", "--batch", "1024"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    one = _bench(1, "--steps", "2", "--warmup", "1", "--batch", "2048")
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 0 and "rehearsal" in two["config"]     # gloo rehearsal: no RCCL
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1
+    for k in ("FER", "BLER", "BER", "FER_exp"):
+        assert two["results"][k] == one["results"][k], (k, two["results"], one["results"])
+    # and a launcher whose world size disagrees with --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, capture_output=True, text=True,
+                         timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
 def test_c2_two_ranks_decode_the_trials_one_rank_decodes():
     """Two ranks x B trials per step cover the trial indices of one rank x 2B: identical error counts."""
     require_gpu()

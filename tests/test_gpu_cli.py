@@ -75,7 +75,7 @@ def test_bp_traj_and_sw_files(B, oracle, tmp_path):
     B.sw_lim_iter(["1", "5", "0", "4", "9", "--L", "12", "--N", "40", "--num-points", "1", "--max-frames", "16",
                    "--batch", "16", "--seed", "5", "--outdir", str(tmp_path), "--quiet"])
     row = open(tmp_path / "SC_LDPC_4_8_L12_M20_BP_SW5_4it_9init_Random_BLER_1.dat").read().strip().split("\n")[1].split()
-    d_adj, d_ch = E.sample_philox(p, 5, 0, 16, 0.475)
+    d_adj, d_ch = E.sample_philox(p, 5, B.trial_key(1, 0), 16, 0.475)             # replica INDEX = 1, point 0, frames 0..15
     A, bits = d_adj.cpu().numpy(), E.unpack_bits(d_ch.cpu().numpy(), p.n)
     ue = fe = 0
     for t in range(16):

@@ -64,6 +64,22 @@ def test_bp_programs_two_ranks_write_the_single_rank_file(tmp_path, prog, args):
     _same_files(str(d1), str(d2), 1)
 
 
+def test_bp_traj_two_ranks_write_the_files_of_index_and_index_plus_one(tmp_path):
+    """bp_traj under torch.distributed: rank r is process INDEX + r of the reference's array job (BPT:2095, file name
+    BPT:2131-2134; NB cell 35:21) — the two-rank job leaves exactly the two files that two single runs leave."""
+    require_gpu()
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir(); d2.mkdir()
+    args = ["0", "0", "1000000", "1", "--L", "20", "--N", "200", "--max-frames", "40", "--min-frame-err", "40", "--batch", "16",
+            "--eps-ini", "0.47", "--seed", "77", "--quiet"]
+    _run(2, "fl_scaling_sc_ldpc_amd.bp_decoding", ["bp_traj", "3", *args, "--outdir", str(d2)])
+    for idx in ("3", "4"):
+        _run(1, "fl_scaling_sc_ldpc_amd.bp_decoding", ["bp_traj", idx, *args, "--outdir", str(d1)])
+    _same_files(str(d1), str(d2), 2)
+    a, b = (open(os.path.join(d2, nm)).read() for nm in sorted(os.listdir(d2)))
+    assert a != b and a.count("\n\n") == 40 and b.count("\n\n") == 40
+
+
 def test_ber_sim_two_ranks_write_the_single_rank_table(tmp_path):
     """ber_sim.py's argv (PD:1327-1356) in throughput mode: the trials of every round split over the ranks, result rows
     all-gathered, ordered stop at max_fuckups; rank 0 writes."""

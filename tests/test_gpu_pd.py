@@ -123,6 +123,66 @@ def test_peel_sweep_equals_oracle_on_device_sampled_inputs(PD, L, M, e, term, bo
     assert t13[5] == T and t13[7] == T * g.generated
 
 
+def test_soft_doping_in_throughput_mode_equals_oracle(PD):
+    """gen_users_sc_ldpc_doping with a dict (PD:176-183: the first int(alpha*M) VNs of a doped position are known) under
+    rng="philox": the device clears those channel bits (scldpc_clear_channel_range_device); totals = the oracle's on the
+    same device-sampled codes with the same bits cleared on the host."""
+    from oracle import pd_oracle as P
+    E = PD.E
+    L, M, e, T = 16, 200, 0.49, 24
+    doping = {3: 0.5, 9: 0.25, 10: 1.0}
+    g = PD._Geometry(4, 8, L, M, True, True, doping)
+    d_adj, d_ch = E.sample_philox(g.params, 123, 0, T, e, adj16=True)
+    A = E.adj16_to_global(g.params, d_adj.cpu().numpy()).astype(np.int64)
+    bits = E.unpack_bits(d_ch.cpu().numpy(), g.params.n).astype(bool)
+    tot = dict(lost=0, lost_exp=0, fe=0, fee=0, blocks=0)
+    for t in range(T):
+        for pos, alpha in doping.items():
+            bits[t, pos * M: pos * M + int(alpha * M)] = False
+        s = P.sc_ldpc_trial_stats(A[t], bits[t], 4, 8, L, M, True, True, doping)
+        tot["lost"] += s["num_lost"]; tot["lost_exp"] += s["num_lost_exp"]; tot["fe"] += s["frame_err"]
+        tot["fee"] += s["frame_err_exp"]; tot["blocks"] += s["blocks_failed_exp"]
+    t13 = PD.simulate_sc_ldpc(e, 4, 8, L, M, True, False, True, False, num_repeats=T, max_fuckups=2000, doping_points=doping,
+                              rng="philox", seed=123, batch=7)
+    assert t13[5] == T and t13[7] == T * g.generated and g.generated == L * M - (100 + 50 + 200)
+    assert (t13[0] * T, t13[4], t13[6], t13[10]) == (tot["fe"], tot["fee"], tot["lost_exp"], tot["blocks"])
+    assert t13[2] == tot["lost"] / (T * g.generated) and tot["fe"] > 0
+    # the range clear itself, at word boundaries
+    import torch
+    p = E.make_params(4, 8, 4, 40)
+    for lo, hi in ((0, 0), (0, 1), (31, 33), (32, 64), (5, 160), (100, 131)):
+        ch = torch.full((3, p.nw), -1, dtype=torch.int32, device="cuda")
+        E.clear_channel_range(p, ch, lo, hi)
+        b = E.unpack_bits(ch.cpu().numpy(), p.n)
+        exp = np.ones(p.n, dtype=np.uint8); exp[lo:hi] = 0
+        assert (b == exp).all(), (lo, hi)
+
+
+def test_ordered_stop_on_the_device_is_independent_of_the_batch(PD):
+    """simulate_sc_ldpc's bookkeeping and stop rule (PD:668-699) run on the device (scldpc_accumulate_peel_device): the
+    13-tuple does not depend on the batch size, equals a literal host loop over the per-trial rows, and the run stops at
+    the trial at which num_fuckups reaches max_fuckups."""
+    E = PD.E
+    L, M, e, T = 12, 40, 0.5, 300
+    g = PD._Geometry(4, 8, L, M, True, True, [])
+    d_adj, d_ch = E.sample_philox(g.params, 5, 0, T, e, adj16=True)
+    out = E.peel_sweep(g.params, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi)["out"].cpu().numpy()
+    for max_f in (1, 7, 50, 10 ** 6):
+        fu = fue = lost = loste = blk = used = 0
+        for t in range(T):
+            used += 1
+            fu += out[t, 0] >= 1; lost += int(out[t, 0]); fue += out[t, 1] > 0; loste += int(out[t, 1]); blk += int(out[t, 2])
+            if fu >= max_f:
+                break
+        exp = (fu / used, fue / used, lost / (used * g.generated), loste / (used * g.generated), fue, used, loste,
+               used * g.generated, blk, used * g.blocks, blk / (used * g.blocks))
+        for batch in (1, 5, 64, 1000):
+            t13 = PD.simulate_sc_ldpc(e, 4, 8, L, M, True, False, True, False, num_repeats=T, max_fuckups=max_f, rng="philox",
+                                      seed=5, batch=batch)
+            assert tuple(_tuple11(t13)) == tuple(float(x) for x in exp), (max_f, batch)
+        assert max_f > 50 or fu == max_f
+
+
 @pytest.mark.parametrize("L,M,e,term", [(10, 20, 0.45, False), (10, 20, 0.5, True), (20, 200, 0.47, False)])
 def test_peel_pick_philox_stream_equals_cpu_twin(PD, oracle, L, M, e, term):
     from oracle import pd_oracle as P
