@@ -40,6 +40,9 @@ EXPORTS = (
     "scldpc_stream_glibc_inputs_host", "scldpc_stream_run_device_inputs", "scldpc_workspace_bytes",
     "scldpc_sw_bp_ring_supported", "scldpc_cn_sockets_device", "scldpc_sw_bp_ring_device",
     "scldpc_accumulate_peel_device", "scldpc_clear_channel_range_device",
+    "scldpc_stream_glibc_next_host", "scldpc_stream_run_device_inputs_at",
+    "scldpc_full_bp_sock16_supported", "scldpc_full_bp_fixpoint_device_sock16", "scldpc_full_bp_device_sock16",
+    "scldpc_full_bp_traj_device_cn16", "scldpc_full_bp_traj_device_sock16",
 )
 
 
@@ -111,6 +114,11 @@ def lib():
     L.scldpc_sample_philox_device_sock16.argtypes = [pp, u64, u64, i32, dbl, i32, vp, vp, vp, vp, vp]
     L.scldpc_full_bp_fixpoint_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, vp, vp, vp]
     L.scldpc_full_bp_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.scldpc_full_bp_sock16_supported.argtypes = [pp]
+    L.scldpc_full_bp_fixpoint_device_sock16.argtypes = L.scldpc_full_bp_fixpoint_device_cn16.argtypes
+    L.scldpc_full_bp_device_sock16.argtypes = L.scldpc_full_bp_device_cn16.argtypes
+    L.scldpc_full_bp_traj_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]
+    L.scldpc_full_bp_traj_device_sock16.argtypes = L.scldpc_full_bp_traj_device_cn16.argtypes
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, u64, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes
@@ -128,6 +136,8 @@ def lib():
     L.scldpc_stream_run_device.argtypes = [pp, i32, u64, u64, dbl, i32, i32, vp, i32, vp, vp, vp, vp]
     L.scldpc_stream_glibc_inputs_host.argtypes = [pp, u32, dbl, i32, vp, i32, vp, vp]
     L.scldpc_stream_run_device_inputs.argtypes = [pp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i64, vp]
+    L.scldpc_stream_glibc_next_host.argtypes = [pp, vp, dbl, i32, vp, i32, i64, i32, vp, vp]
+    L.scldpc_stream_run_device_inputs_at.argtypes = [pp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, i64, vp]
     L.scldpc_sw_bp_ring_supported.argtypes = [pp, i32]
     L.scldpc_cn_sockets_device.argtypes = [pp, i32, vp, vp, vp]
     L.scldpc_sw_bp_ring_device.argtypes = [pp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]

@@ -160,8 +160,10 @@ class Simulator:
         # full BP on the BASELINE ensemble family: the second-generation pair (sampler_v2 + the 4-bits-per-CN decoder) needs
         # the CN -> VN table next to the VN -> CN one.  gen2: unlimited, no iteration statistics (fixpoint); lvl2: the same
         # decoder walked one flooding iteration per round — iteration caps (the published ..._500it_... tables) and counts
-        cn16 = self.rng == "philox" and self.decoder == "full" and self.rows_cap == 0 and E.cn16_supported(p)
-        self.gen2 = cn16 and self.schedule == "fixpoint" and (self.max_it <= 0 or self.max_it >= 1000000)
+        small = self.rng == "philox" and self.decoder == "full"
+        self.sock = small and not E.cn16_supported(p) and E.full_bp_sock16_supported(p)    # n >= 65535: CN -> socket table
+        cn16 = small and (E.cn16_supported(p) or self.sock)
+        self.gen2 = cn16 and self.rows_cap == 0 and self.schedule == "fixpoint" and (self.max_it <= 0 or self.max_it >= 1000000)
         self.lvl2 = cn16 and not self.gen2
         # square-window decoding with the window's state in LDS reads a CN -> socket table: sampled with the code where the
         # second-generation sampler takes the ensemble (else E.sw_bp builds it in a pass of its own)
@@ -178,7 +180,8 @@ class Simulator:
             return ("sampler_v2 (CN->socket table) + sw_ring (window state in LDS)" if self.ring2 else
                     "sampler (first generation) + " + ("sw_ring + cn_sockets pass" if E.sw_ring_supported(self.p, self.W)
                                                        and self.d_adj.dtype == torch.int16 else "sw_bp (whole chain)"))
-        samp = "glibc replay on the host" if self.rng == "glibc" else "sampler_v2 (CN->VN table)" if (self.gen2 or self.lvl2) \
+        samp = "glibc replay on the host" if self.rng == "glibc" else \
+            ("sampler_v3 (CN->socket table)" if self.sock else "sampler_v3 (CN->VN table)") if (self.gen2 or self.lvl2) \
             else "sampler (first generation)"
         if self.gen2:
             return samp + " + full_bp_small fixpoint (4-bit CN counts)"
@@ -200,16 +203,20 @@ class Simulator:
             return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt,
                            d_cn_sock=self.d_cn[:nb] if self.ring2 else None)
         if self.gen2 and not want_rows:
-            return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt)
-        if self.lvl2 and not want_rows:
-            return E.full_bp_cn16(self.p, adj, self.d_cn[:nb], ch, max_it=self.max_it, is_term=self.is_term, counters=cnt)
+            return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt, sockets=self.sock)
+        if self.lvl2:
+            return E.full_bp_cn16(self.p, adj, self.d_cn[:nb], ch, max_it=self.max_it, is_term=self.is_term, counters=cnt,
+                                  sockets=self.sock, rows_cap=self.rows_cap if want_rows else 0)
         if self.schedule == "fixpoint" and not want_rows and (self.max_it <= 0 or self.max_it >= 1000000):
             return E.full_bp_fixpoint(self.p, adj, ch, is_term=self.is_term, counters=cnt)    # no iteration counts
         return E.full_bp(self.p, adj, ch, max_it=self.max_it, is_term=self.is_term,
                          rows_cap=self.rows_cap if want_rows else 0, counters=cnt)
 
     def fill_batch(self, sim, eps, frame0, nb):
-        if self.rng == "philox" and (self.gen2 or self.lvl2):
+        if self.rng == "philox" and (self.gen2 or self.lvl2) and self.sock:
+            E.sample_philox_sock16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
+                                   out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
+        elif self.rng == "philox" and (self.gen2 or self.lvl2):
             E.sample_philox_cn16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
                                  out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox" and self.ring2:
@@ -537,6 +544,31 @@ def run_streaming(index, W, doped, opts):
     device = E.local_device()
     os.makedirs(opts.outdir, exist_ok=True)
     path = os.path.join(opts.outdir, stream_filename(p, len(doped), W, index))
+    if getattr(opts, "rng", "philox") == "glibc":
+        # The reference's own experiment, row for row: ONE stream, ONE srandom(seed), the points back to back with random()
+        # carried over, every point stopped at the very position at which main_streaming stops (BPF:2033).
+        if world > 1:
+            raise SystemExit("--rng glibc replays the reference's one sequential random() stream: run it as a single process")
+        run = E.GlibcStreamRun(p, opts.seed, W, doped, device=device)
+
+        def tripped(c):
+            return c[3] >= opts.max_blocks_err or c[7] >= opts.max_blocks
+
+        for sim in range(grid.num_points):
+            eps = grid.eps(sim)
+            run.new_point(eps)
+            while True:
+                rows = run.run(opts.chunk, stop=tripped)
+                if tripped(rows[-1, 2:]):
+                    break
+            tot = rows[-1, 2:]
+            with open(path, "w" if sim == 0 else "a") as f:
+                if sim == 0:
+                    f.write(STREAM_HEADER)
+                f.write(stream_row(eps, tot))
+            if not opts.quiet:
+                print("%f %e %e %e %e" % (eps, tot[0] / tot[4], tot[1] / tot[5], tot[2] / tot[6], tot[3] / tot[7]), flush=True)
+        return 0
     for sim in range(grid.num_points):
         eps = grid.eps(sim)
         st = E.Streams(p, opts.streams, opts.seed, eps, W, doped,
@@ -574,7 +606,10 @@ def streaming(argv=None):
     ap.add_argument("--num-points", type=int, default=0)
     ap.add_argument("--max-blocks-err", type=int, default=1000, help="Def_MaxNumberBlocksError (BPF:41)")
     ap.add_argument("--max-blocks", type=int, default=1000000, help="Def_MaxNumberBlocksSim (BPF:42)")
-    ap.add_argument("--streams", type=int, default=512, help="independent streams per rank")
+    ap.add_argument("--streams", type=int, default=512, help="independent streams per rank (--rng philox)")
+    ap.add_argument("--rng", choices=("philox", "glibc"), default="philox",
+                    help="glibc: the reference's own experiment — one stream drawn from srandom(--seed) exactly as "
+                         "main_streaming draws it (BPF:1942-1945), reproduced row for row; single process")
     ap.add_argument("--chunk", type=int, default=64, help="positions per stream and launch")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--outdir", default=".")

@@ -35,7 +35,7 @@ using namespace scldpc_dev;
 
 enum { SC_NE = 0, SC_REM, SC_N0, SC_N1, SC_OVF, SC_Q, SC_N = 8 };
 // LEVEL: per-iteration counters rotated three ways, so that one barrier per iteration is enough (as in full_bp.hip)
-enum { LV_VALID = 2, LV_PUSH = 6, LV_DROP = 9, LV_REM = 12, LV_OVF = 15, LV_N = 18 };
+enum { LV_VALID = 2, LV_EXTRA0 = 3, LV_PUSH = 6, LV_DROP = 9, LV_REM = 12, LV_OVF = 15, LV_N = 18 };
 
 struct SmArgs {
     int L, V, C, n, nk, cn_lim, nw, ncw;            // ncw = words of 8 count nibbles
@@ -43,16 +43,22 @@ struct SmArgs {
     int ntrials;                                    // workgroup b decodes trials b, b + gridDim.x, …
     int kswitch;                                    // frontier width below which the waves go private
     int max_it;                                     // LEVEL: MaxNumIt, <= 0 = unlimited
+    int rows_cap;                                   // TRAJ: rows kept per trial
+    int32_t *rows;                                  // TRAJ: [T][rows_cap][3] = deg_1_iter, recovered, first erased position
     int off_U, off_q0, off_q1, off_pos, off_scal, off_fb, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
     const uint16_t *vn_adj16;                       // [T][n][4]   CN index local to its position
-    const uint16_t *cn_adj16;                       // [T][nk][8]  VNs of every CN (0xFFFF: none)
+    const uint16_t *cn_adj16;                       // [T][nk][8]  VNs of every CN (0xFFFF: none); SOCK: their sockets dv*t + i instead
     const uint32_t *chan;
     int32_t *counters;
     uint32_t *erased_out;
 };
 
 // Seven 4-wave workgroups per CU are 7 waves per SIMD: at most 96 SGPRs and 72 VGPRs per wave (MI355X_MICROARCH.md).
-template <int BLOCK, bool LEVEL, bool PERSIST>
+// SOCK: the CN -> VN table holds sockets (s = dv*t + i = edge i of VN t of position CNpos - i: scldpc_sample_philox_device_sock16's
+// table, any chain length) instead of global VN ids (which need n < 65535).
+// TRAJ (with LEVEL): the trajectory rows of the BPT build — per iteration deg_1_iter, the VNs recovered and the position of
+// the first erased VN (BPT:988, 1037-1038, 1051), incl. iteration 0's count of degree-1 CNs whose only VN is known (BPF:973).
+template <int BLOCK, bool LEVEL, bool PERSIST, bool SOCK, bool TRAJ = false>
 __global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
 {
     constexpr int kWaves = BLOCK / 64;
@@ -121,15 +127,23 @@ __global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void
     auto step = [&](int c, uint32_t (&out)[4]) {
         out[0] = out[1] = out[2] = out[3] = 0;
         const uint4 s4 = crow[c];
-        const uint32_t jk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
-                                s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
+        uint32_t jk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
+                          s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
+        bool none[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) none[k] = jk[k] == 0xFFFFu;
+        if constexpr (SOCK) {                                            // socket -> global VN index
+            const int vbase = (int)__umulhi((uint32_t)c, a.magic_c) * V;                   // CN position * V
+#pragma unroll
+            for (int k = 0; k < 8; k++) jk[k] = (uint32_t)(vbase - (int)(jk[k] & 3u) * V) + (jk[k] >> 2);
+        }
         uint32_t wd[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) wd[k] = U[min(jk[k] >> 5, (uint32_t)nw - 1u)];      // 0xFFFF (no VN): any word, masked below
+        for (int k = 0; k < 8; k++) wd[k] = U[none[k] ? 0u : jk[k] >> 5];               // no VN: any word, masked below
         int j = -1;
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if (jk[k] != 0xFFFFu && ((wd[k] >> (jk[k] & 31u)) & 1u)) j = (int)jk[k];
+            if (!none[k] && ((wd[k] >> (jk[k] & 31u)) & 1u)) j = (int)jk[k];
         if (j < 0) return;                                               // its last neighbour is being released elsewhere
         const uint2 r = vrow[j];                                         // issued before the claim: overlaps its round trip
         const uint32_t bit = 1u << (j & 31);
@@ -177,7 +191,24 @@ __global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void
     if constexpr (LEVEL) {
         // ---- one flooding iteration per barrier round (decodeBP's do-while, BPF:927-1065) ------------------------------
         uint8_t *fb = reinterpret_cast<uint8_t *>(lds + a.off_fb);       // snapshot of a scan round: one byte per count word
-        int prec = n, iter = 0, ncur = 0, nfront = 0;
+        int prec = n, iter = 0, ncur = 0, nfront = 0, first_word = 0;
+        if constexpr (TRAJ) {
+            // degree-1 CNs whose single VN is known count into iteration 0's deg_1_iter (BPF:969-978).  Only the first and the
+            // last dv-1 CN positions of the chain hold CNs of degree below dc: their rows say how many neighbours they have.
+            int extra = 0;
+            const int head = 3 * C, tail0 = L * C;
+            for (int i = tid; i < 2 * head; i += BLOCK) {
+                const int c = i < head ? i : tail0 + (i - head);
+                if (c >= cn_lim || c >= nk) continue;
+                const uint4 s4 = crow[c];
+                const int deg = ((s4.x & 0xFFFFu) != 0xFFFFu) + ((s4.x >> 16) != 0xFFFFu) + ((s4.y & 0xFFFFu) != 0xFFFFu) +
+                                ((s4.y >> 16) != 0xFFFFu) + ((s4.z & 0xFFFFu) != 0xFFFFu) + ((s4.z >> 16) != 0xFFFFu) +
+                                ((s4.w & 0xFFFFu) != 0xFFFFu) + ((s4.w >> 16) != 0xFFFFu);
+                extra += deg == 1 && ((cnt[c >> 3] >> ((c & 7) * 4)) & 15u) == 0u;
+            }
+            extra = wave_sum(extra);
+            if (lane == 0 && extra) atomicAdd(&scal[LV_EXTRA0], extra);
+        }
         bool scan = true;                                                // iteration 0 has no queue yet
         ne = nch;
         for (;;) {
@@ -253,9 +284,33 @@ __global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void
             if (overflow) scal[LV_OVF + g] = 1;
             __syncthreads();                                             // end of flooding iteration `iter`
             // ---- bookkeeping, identical in every thread (full_bp.hip)
-            const int deg1 = nfront;                                     // deg_1_iter, BPF:969-978
+            const int deg1 = nfront + ((TRAJ && iter == 0) ? scal[LV_EXTRA0] : 0);      // deg_1_iter, BPF:969-978
             ne -= scal[LV_REM + g];
             const int recovered = prec - ne;
+            if constexpr (TRAJ) {
+                if (wave == 0 && a.rows && rounds < a.rows_cap) {
+                    // first erased VN (BPT:1037-1038): U only loses bits, so resume from the last hit
+                    int fw = first_word, first = n;
+                    while (fw < nw) {
+                        const uint32_t w = (fw + lane < nw) ? U[fw + lane] : 0u;
+                        const unsigned long long m = __ballot(w != 0u);
+                        if (m) {
+                            const int l0 = __ffsll((long long)m) - 1;
+                            const uint32_t w0 = (uint32_t)__shfl((int)w, l0, 64);
+                            fw += l0;
+                            first = fw * 32 + (__ffs((int)w0) - 1);
+                            break;
+                        }
+                        fw += 64;
+                    }
+                    first_word = fw;
+                    if (lane == 0) {
+                        int32_t *r = a.rows + ((size_t)trial * a.rows_cap + rounds) * 3;
+                        r[0] = deg1; r[1] = recovered; r[2] = (int)__umulhi((uint32_t)first, a.magic_v);
+                    }
+                }
+                __syncthreads();                                         // wave 0 read U above: the next round's releases stay behind it
+            }
             rounds++;
             if (deg1 < recovered && iter > 0) { status = -1; break; }    // BPF:1035-1039
             if (ne == 0 || ne == prec) break;                            // BPF:1044-1045
@@ -394,8 +449,10 @@ __global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void
                                             s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
                     int other = -1;
                     for (int k = 0; k < 8; k++) {
-                        const int j2 = (int)jk[k];
-                        if (j2 != 0xFFFF && j2 != j && ((U[j2 >> 5] >> (j2 & 31)) & 1u)) other = j2;
+                        if (jk[k] == 0xFFFFu) continue;
+                        // (cc[i] lies in CN position q0 + i)
+                        const int j2 = SOCK ? (q0 + i - (int)(jk[k] & 3u)) * V + (int)(jk[k] >> 2) : (int)jk[k];
+                        if (j2 != j && ((U[j2 >> 5] >> (j2 & 31)) & 1u)) other = j2;
                     }
                     if (other < 0 || (i > 0 && other != partner)) pair = false;
                     partner = other;
@@ -466,26 +523,43 @@ constexpr int kSwitchWidth = 128;       // frontier entries below which the wave
 
 }  // namespace
 
-// 1 when scldpc_full_bp_fixpoint_device_cn16 takes this ensemble
-extern "C" int scldpc_full_bp_cn16_supported(const scldpc_code_params *p)
+namespace {
+bool small_shape(const scldpc_code_params *p)
 {
-    if (scldpc::check_params(p)) return 0;
+    if (scldpc::check_params(p)) return false;
     SmArgs a{};
     uint32_t m;
-    return p->dv == 4 && p->dc == 8 && p->cns_pos <= 65536 && scldpc::nk_of(p) <= 65536 && scldpc::n_of(p) < 65535 &&
-           make_args(p, 1, &a, 4) == 0 && scldpc::magic_of(p->vns_pos, scldpc::n_of(p) + 32, &m) &&
+    // queue entries are 16-bit CN ids; the per-trial state (4 bits per CN, one bit per VN) must fit the LDS
+    return p->dv == 4 && p->dc == 8 && p->cns_pos <= 65536 && scldpc::nk_of(p) <= 65536 &&
+           make_args(p, 1, &a, 1) == 0 && scldpc::magic_of(p->vns_pos, scldpc::n_of(p) + 32, &m) &&
            scldpc::magic_of(p->cns_pos, scldpc::nk_of(p), &m);
+}
+}  // namespace
+
+// 1 when scldpc_full_bp_fixpoint_device_cn16 takes this ensemble (global VN ids in the CN -> VN table: n < 65535)
+extern "C" int scldpc_full_bp_cn16_supported(const scldpc_code_params *p)
+{
+    return small_shape(p) && scldpc::n_of(p) < 65535;
+}
+
+// 1 when the _sock16 forms take this ensemble (sockets in the CN -> VN table: any n whose state fits the LDS)
+extern "C" int scldpc_full_bp_sock16_supported(const scldpc_code_params *p)
+{
+    return small_shape(p) && (int64_t)p->vns_pos * p->dv <= 65535;
 }
 
 namespace {
 
-int launch_small(const char *who, bool level, const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+int launch_small(const char *who, bool level, bool sock, const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
                  const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
-                 int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+                 int32_t *d_counters, uint32_t *d_erased_bits, void *stream, int32_t *d_rows = nullptr, int32_t rows_cap = 0)
 {
+    if (d_rows && (rows_cap <= 0 || !level))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: d_rows given but rows_cap <= 0", who);
     if (int rc = scldpc::check_params(p)) return rc;
-    if (!scldpc_full_bp_cn16_supported(p))
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 65536 CNs and fewer than 65535 VNs per trial", who);
+    if (!(sock ? scldpc_full_bp_sock16_supported(p) : scldpc_full_bp_cn16_supported(p)))
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: takes dv = 4, dc = 8, at most 65536 CNs per trial%s", who,
+                                 sock ? " and 16-bit sockets" : " and fewer than 65535 VNs (use the _sock16 form beyond)");
     if (ntrials < 0 || (ntrials > 0 && (!d_counters || !d_vn_adj16 || !d_cn_adj16 || !d_chan_bits)))
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null buffer or negative ntrials", who);
     if (ntrials == 0) return SCLDPC_OK;
@@ -500,10 +574,14 @@ int launch_small(const char *who, bool level, const scldpc_code_params *p, int32
     a.counters = d_counters; a.erased_out = d_erased_bits;
     a.kswitch = kSwitchWidth;
     a.ntrials = ntrials;
+    a.rows = d_rows; a.rows_cap = d_rows ? rows_cap : 0;
     a.max_it = max_it;
     const int grid = scldpc::debug_grid("DECODER", ntrials);
-    void (*kern)(const SmArgs) = grid < ntrials ? (level ? full_bp_small_kernel<kBlockSmall, true, true> : full_bp_small_kernel<kBlockSmall, false, true>)
-                                                : (level ? full_bp_small_kernel<kBlockSmall, true, false> : full_bp_small_kernel<kBlockSmall, false, false>);
+    void (*kern)(const SmArgs) = sock ? (level ? full_bp_small_kernel<kBlockSmall, true, false, true> : full_bp_small_kernel<kBlockSmall, false, false, true>)
+        : grid < ntrials ? (level ? full_bp_small_kernel<kBlockSmall, true, true, false> : full_bp_small_kernel<kBlockSmall, false, true, false>)
+                         : (level ? full_bp_small_kernel<kBlockSmall, true, false, false> : full_bp_small_kernel<kBlockSmall, false, false, false>);
+    if (sock && grid < ntrials) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: no persistent form with the socket table", who);
+    if (d_rows) kern = sock ? full_bp_small_kernel<kBlockSmall, true, false, true, true> : full_bp_small_kernel<kBlockSmall, true, false, false, true>;
     size_t lds_bytes = 4u * (size_t)a.total;
     lds_bytes = std::min(lds_bytes + scldpc::debug_lds_pad("DECODER"), (size_t)scldpc::kMaxLdsBytes);
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
@@ -519,7 +597,7 @@ extern "C" int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, 
                                                    const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
                                                    uint32_t *d_erased_bits, void *stream)
 {
-    return launch_small("scldpc_full_bp_fixpoint_device_cn16", false, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, 0,
+    return launch_small("scldpc_full_bp_fixpoint_device_cn16", false, false, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, 0,
                         is_term, d_counters, d_erased_bits, stream);
 }
 
@@ -528,6 +606,47 @@ extern "C" int scldpc_full_bp_device_cn16(const scldpc_code_params *p, int32_t n
                                           const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it,
                                           int32_t is_term, int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
 {
-    return launch_small("scldpc_full_bp_device_cn16", true, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, max_it,
+    return launch_small("scldpc_full_bp_device_cn16", true, false, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, max_it,
                         is_term, d_counters, d_erased_bits, stream);
+}
+
+// The same two decoders reading the CN -> SOCKET table of scldpc_sample_philox_device_sock16 / scldpc_cn_sockets_device
+// (position-local 16-bit sockets): no limit on the number of VNs per trial — e.g. the published L = 100, N = 1000 runs.
+extern "C" int scldpc_full_bp_fixpoint_device_sock16(const scldpc_code_params *p, int32_t ntrials,
+                                                     const uint16_t *d_vn_adj16, const uint16_t *d_cn_sock16,
+                                                     const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
+                                                     uint32_t *d_erased_bits, void *stream)
+{
+    return launch_small("scldpc_full_bp_fixpoint_device_sock16", false, true, p, ntrials, d_vn_adj16, d_cn_sock16, d_chan_bits,
+                        0, is_term, d_counters, d_erased_bits, stream);
+}
+
+extern "C" int scldpc_full_bp_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                            const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t max_it,
+                                            int32_t is_term, int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
+{
+    return launch_small("scldpc_full_bp_device_sock16", true, true, p, ntrials, d_vn_adj16, d_cn_sock16, d_chan_bits, max_it,
+                        is_term, d_counters, d_erased_bits, stream);
+}
+
+// decodeBP of the trajectory build (BPT:900-1140): the iterations with their rows — deg_1_iter, VNs recovered, position of the
+// first erased VN (BPT:988, 1037-1038, 1051) — d_rows int32 [ntrials][rows_cap][3], d_counters[ITERATIONS] rows per trial.
+extern "C" int scldpc_full_bp_traj_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                               const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it,
+                                               int32_t is_term, int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                                               uint32_t *d_erased_bits, void *stream)
+{
+    if (!d_rows) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_traj_device_cn16: null d_rows");
+    return launch_small("scldpc_full_bp_traj_device_cn16", true, false, p, ntrials, d_vn_adj16, d_cn_adj16, d_chan_bits, max_it,
+                        is_term, d_counters, d_erased_bits, stream, d_rows, rows_cap);
+}
+
+extern "C" int scldpc_full_bp_traj_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                                 const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t max_it,
+                                                 int32_t is_term, int32_t *d_counters, int32_t *d_rows, int32_t rows_cap,
+                                                 uint32_t *d_erased_bits, void *stream)
+{
+    if (!d_rows) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_traj_device_sock16: null d_rows");
+    return launch_small("scldpc_full_bp_traj_device_sock16", true, true, p, ntrials, d_vn_adj16, d_cn_sock16, d_chan_bits, max_it,
+                        is_term, d_counters, d_erased_bits, stream, d_rows, rows_cap);
 }

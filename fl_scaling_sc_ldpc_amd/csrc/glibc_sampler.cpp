@@ -150,20 +150,27 @@ extern "C" int scldpc_sample_glibc_host(const scldpc_code_params *p, uint32_t se
 // Decoding draws nothing, so the whole input stream is a function of (seed, eps, doping) alone.
 //   inter_out uint16 [npos_gen + dv - 1][S]: CN-local id perm_code[i] / dc of socket i of CN position c
 //   chan_out  uint32 [npos_gen][ceil(vns_pos/32)]: bit t of position g = 1 iff VN (g, t) is erased
-extern "C" int scldpc_stream_glibc_inputs_host(const scldpc_code_params *p, uint32_t seed, double eps, int32_t ndoped,
-                                               const int32_t *doped_positions, int32_t npos_gen, uint16_t *inter_out,
-                                               uint32_t *chan_out)
+// The same draws from a CARRIED state (scldpc_glibc_state_init / _reset_perm: random() and perm_code), so that a run of any
+// length — and a run over several ε points, which main_streaming draws from ONE srandom (BPF:1942-1945) with inizio_sim's
+// perm_code reset and initialize_arrays_circular's dv-1 shuffles at the start of every point (BPF:1994-1998) — is replayed
+// in pieces: first `ninit` CN positions are shuffled (dv-1 at the start of a point, 0 afterwards), then
+// generate_stream_pos(gpos0 + k), k < npos: one more CN position shuffled, the channel of VN position gpos0 + k drawn.
+extern "C" int scldpc_stream_glibc_next_host(const scldpc_code_params *p, void *state, double eps, int32_t ndoped,
+                                             const int32_t *doped_positions, int32_t ninit, int64_t gpos0, int32_t npos,
+                                             uint16_t *inter_out, uint32_t *chan_out)
 {
     if (int rc = scldpc::check_params(p)) return rc;
-    if (npos_gen < 0 || !inter_out || !chan_out || ndoped < 0 || (ndoped > 0 && !doped_positions))
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_glibc_inputs_host: null buffer or negative count");
-    const int dv = p->dv, dc = p->dc, S = p->cns_pos * dc, V = p->vns_pos, wpp = (V + 31) / 32;
+    if (!state || npos < 0 || ninit < 0 || gpos0 < 0 || ((npos > 0 || ninit > 0) && !inter_out) || (npos > 0 && !chan_out) ||
+        ndoped < 0 || (ndoped > 0 && !doped_positions))
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_glibc_next_host: null buffer or negative count");
+    const int dc = p->dc, S = p->cns_pos * dc, V = p->vns_pos, wpp = (V + 31) / 32;
     if (p->cns_pos > 65536)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_glibc_inputs_host: cns_pos > 65536");
-    GlibcRandom g;
-    g.seed(seed);
-    std::vector<int32_t> perm((size_t)S);
-    for (int i = 0; i < S; i++) perm[i] = i;                                 // inizio_sim, BPF:308-311
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_glibc_next_host: cns_pos > 65536");
+    StateHeader *st = static_cast<StateHeader *>(state);
+    if (st->nsock != S)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "state blob was initialised for a different ensemble");
+    GlibcRandom &g = st->rng;
+    int32_t *perm = perm_of(state);
     auto shuffle_into = [&](uint16_t *row) {
         for (int i = 0; i < S; i++) {                                          // BPF:1770-1776
             const int pick = i + g.next() % (S - i);
@@ -171,23 +178,37 @@ extern "C" int scldpc_stream_glibc_inputs_host(const scldpc_code_params *p, uint
         }
         for (int i = 0; i < S; i++) row[i] = (uint16_t)(perm[i] / dc);         // BPF:1782
     };
-    auto doped = [&](int pos) {                                                // BPF:1589-1612
+    auto doped = [&](long long pos) {                                          // BPF:1589-1612
         if (ndoped == 0) return false;
-        const int period = doped_positions[ndoped - 1] + 1, m = pos % period;
+        const int period = doped_positions[ndoped - 1] + 1, m = (int)(pos % period);
         if (m < doped_positions[0]) return false;
         for (int d = 0; d < ndoped; d++) if (m == doped_positions[d]) return true;
         return false;
     };
-    for (int c = 0; c < dv - 1; c++) shuffle_into(inter_out + (size_t)c * S);
-    memset(chan_out, 0, sizeof(uint32_t) * (size_t)npos_gen * wpp);
-    for (int gpos = 0; gpos < npos_gen; gpos++) {
-        shuffle_into(inter_out + (size_t)(gpos + dv - 1) * S);
-        if (doped(gpos)) continue;                                             // no draws for a doped position
-        uint32_t *row = chan_out + (size_t)gpos * wpp;
+    for (int c = 0; c < ninit; c++) shuffle_into(inter_out + (size_t)c * S);
+    if (npos > 0) memset(chan_out, 0, sizeof(uint32_t) * (size_t)npos * wpp);
+    for (int k = 0; k < npos; k++) {
+        shuffle_into(inter_out + (size_t)(ninit + k) * S);
+        if (doped(gpos0 + k)) continue;                                        // no draws for a doped position
+        uint32_t *row = chan_out + (size_t)k * wpp;
         for (int t = 0; t < V; t++) {
             const double u = (double)g.next() / 2147483647.0;                 // unif_ch, BPF:360-371
             if (!(u >= eps)) row[t >> 5] |= 1u << (t & 31);
         }
     }
     return SCLDPC_OK;
+}
+
+extern "C" int scldpc_stream_glibc_inputs_host(const scldpc_code_params *p, uint32_t seed, double eps, int32_t ndoped,
+                                               const int32_t *doped_positions, int32_t npos_gen, uint16_t *inter_out,
+                                               uint32_t *chan_out)
+{
+    const int64_t bytes = scldpc_glibc_state_bytes(p);
+    if (bytes < 0) return (int)bytes;
+    if (npos_gen < 0 || !inter_out || !chan_out)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_glibc_inputs_host: null buffer or negative count");
+    std::vector<char> state((size_t)bytes);
+    if (int rc = scldpc_glibc_state_init(p, seed, state.data())) return rc;   // srandom(seed) + inizio_sim's perm_code
+    return scldpc_stream_glibc_next_host(p, state.data(), eps, ndoped, doped_positions, p->dv - 1, 0, npos_gen, inter_out,
+                                         chan_out);
 }

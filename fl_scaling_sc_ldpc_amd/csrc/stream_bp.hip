@@ -50,6 +50,7 @@ struct Args {
     const uint16_t *ext_inter;
     const uint32_t *ext_chan;
     int ext_npos;
+    long long ext_pos0;         // first generated position the two arrays hold
     char *state;
     long long *counters_out;    // [nstreams][10]
     int32_t *trace;             // optional [nstreams][npos][10]
@@ -107,7 +108,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
     auto rank_position = [&](long long cpos) {
         if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
-            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)cpos) * S;
+            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
             uint16_t *dst = inter + (size_t)(cpos % dv) * S;
             for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
             __syncthreads();
@@ -245,7 +246,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
             uint32_t word = 0;
             if (a.ext_chan) {
-                word = a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)g) * wpp + w];     // doped positions: all zero
+                word = a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)(g - a.ext_pos0)) * wpp + w];     // doped positions: all zero
             } else if (!doped) {
 #pragma unroll
                 for (int c8 = 0; c8 < 8; c8++) {
@@ -489,7 +490,7 @@ extern "C" int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_
 static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t seed, uint64_t stream0,
                       double eps, int32_t W, int32_t ndoped, const int32_t *doped_positions,
                       int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace,
-                      const uint16_t *d_ext_inter, const uint32_t *d_ext_chan, int32_t ext_npos, void *stream)
+                      const uint16_t *d_ext_inter, const uint32_t *d_ext_chan, int32_t ext_npos, int64_t ext_pos0, void *stream)
 {
     if (int rc = check_stream(p, W, "scldpc_stream_run_device")) return rc;
     if (nstreams < 0 || npos < 0 || (nstreams > 0 && !d_state))
@@ -522,7 +523,7 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     }
     make_state_layout(p, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
-    a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos;
+    a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos; a.ext_pos0 = ext_pos0;
     const int rows = a.nb / kThreads;
     const size_t lds_bytes = 4u * ((size_t)a.nb / 2 + 2 * kQCap + 32 + kMaxL + S_NSCAL + 2 * 8) + (((size_t)a.S + 15) & ~(size_t)15);
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
@@ -540,7 +541,30 @@ extern "C" int scldpc_stream_run_device(const scldpc_code_params *p, int32_t nst
                                         int32_t npos, void *d_state, int64_t *d_counters, int32_t *d_trace, void *stream)
 {
     return stream_run(p, nstreams, seed, stream0, eps, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
-                      nullptr, nullptr, 0, stream);
+                      nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int scldpc_stream_run_device_inputs_at(const scldpc_code_params *p, int32_t nstreams, int32_t W, int32_t ndoped,
+                                                  const int32_t *doped_positions, int32_t npos, void *d_state,
+                                                  int64_t *d_counters, int32_t *d_trace, const uint16_t *d_inter,
+                                                  const uint32_t *d_chan_bits, int64_t inputs_pos0, int32_t inputs_npos,
+                                                  int64_t positions_done, void *stream)
+{
+    const char *who = "scldpc_stream_run_device_inputs";
+    if (!d_inter || !d_chan_bits || inputs_npos < 0 || positions_done < 0 || inputs_pos0 < 0)
+        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: null inputs or negative count", who);
+    if (p && npos > 0) {
+        // a stream is generated L/2 positions ahead and one more per decoded position (BPF:2001-2012, 2036-2045)
+        const int64_t lo = positions_done == 0 ? 0 : (int64_t)p->L / 2 + positions_done;
+        const int64_t hi = (int64_t)p->L / 2 + positions_done + npos;       // one past the last generated position needed
+        if (lo < inputs_pos0 || hi > inputs_pos0 + inputs_npos)
+            return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: decoding positions %lld .. %lld needs the generated positions "
+                                     "%lld .. %lld, the inputs hold %lld .. %lld", who, (long long)positions_done,
+                                     (long long)(positions_done + npos - 1), (long long)lo, (long long)(hi - 1),
+                                     (long long)inputs_pos0, (long long)(inputs_pos0 + inputs_npos - 1));
+    }
+    return stream_run(p, nstreams, 0, 0, 0.0, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
+                      d_inter, d_chan_bits, inputs_npos, inputs_pos0, stream);
 }
 
 extern "C" int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int32_t nstreams, int32_t W, int32_t ndoped,
@@ -549,13 +573,6 @@ extern "C" int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int3
                                                const uint32_t *d_chan_bits, int32_t inputs_npos, int64_t positions_done,
                                                void *stream)
 {
-    if (!d_inter || !d_chan_bits || inputs_npos < 0 || positions_done < 0)
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device_inputs: null inputs or negative count");
-    // a stream is generated L/2 positions ahead and one more per decoded position (BPF:2001-2012, 2036-2045)
-    if (p && (int64_t)p->L / 2 + positions_done + npos > (int64_t)inputs_npos)
-        return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_stream_run_device_inputs: %lld + %d decoded positions need "
-                                 "%lld generated ones, the inputs hold %d", (long long)positions_done, npos,
-                                 (long long)p->L / 2 + positions_done + npos, inputs_npos);
-    return stream_run(p, nstreams, 0, 0, 0.0, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
-                      d_inter, d_chan_bits, inputs_npos, stream);
+    return scldpc_stream_run_device_inputs_at(p, nstreams, W, ndoped, doped_positions, npos, d_state, d_counters, d_trace,
+                                              d_inter, d_chan_bits, 0, inputs_npos, positions_done, stream);
 }

@@ -301,8 +301,14 @@ def full_bp_fixpoint(p, d_adj, d_chan, is_term=True, want_erased=False, counters
     return {"counters": counters, "rows": None, "erased": erased}
 
 
-def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=False, counters=None):
-    """scldpc_full_bp_fixpoint_device_cn16: full_bp_fixpoint's counters from the VN -> CN and CN -> VN tables."""
+def full_bp_sock16_supported(p):
+    """The (4,8) chain with at most 65536 CNs per trial, any number of VNs: sampler (CN -> socket table) + 4-bits-per-CN decoder."""
+    return bool(lib().scldpc_sample_philox_sock16_supported(C.byref(p))) and bool(lib().scldpc_full_bp_sock16_supported(C.byref(p)))
+
+
+def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=False, counters=None, sockets=False):
+    """scldpc_full_bp_fixpoint_device_cn16: full_bp_fixpoint's counters from the VN -> CN and CN -> VN tables
+    (sockets=True: the CN -> socket table, scldpc_full_bp_fixpoint_device_sock16)."""
     _require_gpu()
     T = d_adj16.shape[0]
     assert d_adj16.is_cuda and d_adj16.dtype == torch.int16 and d_adj16.is_contiguous()
@@ -313,13 +319,14 @@ def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=
     if counters is None:
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
-    check(lib().scldpc_full_bp_fixpoint_device_cn16(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(),
-                                                    1 if is_term else 0, counters.data_ptr(),
-                                                    erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    fn = lib().scldpc_full_bp_fixpoint_device_sock16 if sockets else lib().scldpc_full_bp_fixpoint_device_cn16
+    check(fn(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(),
+             1 if is_term else 0, counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
     return {"counters": counters, "rows": None, "erased": erased}
 
 
-def full_bp_cn16(p, d_adj16, d_cn16, d_chan, max_it=0, is_term=True, want_erased=False, counters=None):
+def full_bp_cn16(p, d_adj16, d_cn16, d_chan, max_it=0, is_term=True, want_erased=False, counters=None, sockets=False,
+                 rows_cap=0):
     """scldpc_full_bp_device_cn16: decodeBP with its iterations (count, cap, stop tests) from the VN -> CN and CN -> VN
     tables — every counter of full_bp (no trajectory rows)."""
     _require_gpu()
@@ -332,9 +339,16 @@ def full_bp_cn16(p, d_adj16, d_cn16, d_chan, max_it=0, is_term=True, want_erased
     if counters is None:
         counters = torch.empty((T, NCOUNTERS), dtype=torch.int32, device=dev)
     erased = torch.empty((T, p.nw), dtype=torch.int32, device=dev) if want_erased else None
-    check(lib().scldpc_full_bp_device_cn16(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(),
-                                           int(max_it), 1 if is_term else 0, counters.data_ptr(),
-                                           erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
+    if rows_cap > 0:                                    # the trajectory build's rows (scldpc_full_bp_traj_device_*)
+        rows = torch.empty((T, rows_cap, 3), dtype=torch.int32, device=dev)
+        fn = lib().scldpc_full_bp_traj_device_sock16 if sockets else lib().scldpc_full_bp_traj_device_cn16
+        check(fn(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(), int(max_it), 1 if is_term else 0,
+                 counters.data_ptr(), rows.data_ptr(), int(rows_cap), erased.data_ptr() if erased is not None else None,
+                 _stream_ptr(dev)))
+        return {"counters": counters, "rows": rows, "erased": erased}
+    fn = lib().scldpc_full_bp_device_sock16 if sockets else lib().scldpc_full_bp_device_cn16
+    check(fn(C.byref(p), T, d_adj16.data_ptr(), d_cn16.data_ptr(), d_chan.data_ptr(), int(max_it), 1 if is_term else 0,
+             counters.data_ptr(), erased.data_ptr() if erased is not None else None, _stream_ptr(dev)))
     return {"counters": counters, "rows": None, "erased": erased}
 
 
@@ -526,6 +540,76 @@ def stream_glibc_inputs(p, seed, eps, doped, npos_gen):
     check(lib().scldpc_stream_glibc_inputs_host(C.byref(p), int(seed) & 0xFFFFFFFF, float(eps), darr.size, dptr, int(npos_gen),
                                                 inter.ctypes.data, chan.ctypes.data))
     return inter, chan
+
+
+class GlibcStreamRun:
+    """main_streaming on the reference's OWN stream (BPF:1934-2054): ONE srandom(seed) for the whole run (BPF:1942-1945),
+    the ε points back to back with random() carried from point to point; the draws are replayed on the host piece by piece
+    (scldpc_stream_glibc_next_host) and decoded on the device (scldpc_stream_run_device_inputs_at).  One stream, as the
+    reference runs it."""
+
+    def __init__(self, p, seed, W, doped=(), device="cuda:0"):
+        _require_gpu()
+        self.p, self.W, self.doped, self.device = p, int(W), tuple(doped), device
+        nbytes = lib().scldpc_glibc_state_bytes(C.byref(p))
+        if nbytes < 0:
+            check(int(nbytes))
+        self._host = np.zeros(nbytes, dtype=np.uint8)
+        check(lib().scldpc_glibc_state_init(C.byref(p), int(seed) & 0xFFFFFFFF, self._host.ctypes.data))     # srandom(seed)
+        self.S, self.wpp = p.cns_pos * p.dc, (p.vns_pos + 31) // 32
+        self.st = None
+
+    def new_point(self, eps):
+        """inizio_sim (perm_code := identity, BPF:308-311) + a fresh buffer (initialize_arrays_circular, BPF:1998)."""
+        check(lib().scldpc_glibc_state_reset_perm(C.byref(self.p), self._host.ctypes.data))
+        self.eps, self.done = float(eps), 0
+        self.st = Streams(self.p, 1, 0, 0.0, self.W, self.doped, device=self.device)
+
+    def _draw(self, ninit, gpos0, npos):
+        inter = np.empty((ninit + npos, self.S), dtype=np.uint16)
+        chan = np.empty((max(npos, 1), self.wpp), dtype=np.uint32)
+        darr, dptr = _lib.doped_array(self.doped)
+        check(lib().scldpc_stream_glibc_next_host(C.byref(self.p), self._host.ctypes.data, self.eps, darr.size, dptr, int(ninit),
+                                                  int(gpos0), int(npos), inter.ctypes.data, chan.ctypes.data))
+        return inter, chan[:npos]
+
+    def run(self, npos, stop=None):
+        """Decode npos further positions.  Returns the trace rows int64 [k, 10] (position, value of decodeBP_SW_circular, the
+        eight running counters) of the positions that count: all npos, or — with stop(counters) -> bool — up to and including
+        the first position at which main_streaming's rule trips (BPF:2033); the host stream is then left exactly where the
+        reference leaves it (it does not generate beyond that position), ready for the next point."""
+        p, dv, half = self.p, self.p.dv, self.p.L // 2
+        snap = self._host.copy()
+        first = self.done == 0
+        g0 = 0 if first else half + self.done
+        ng = (half if first else 0) + npos
+        inter, chan = self._draw(dv - 1 if first else 0, g0, ng)
+        d_inter = torch.zeros((1, ng + dv - 1, self.S), dtype=torch.int16, device=self.device)
+        d_inter[0, (0 if first else dv - 1):] = torch.from_numpy(inter.view(np.int16)).to(self.device)
+        d_chan = torch.from_numpy(np.ascontiguousarray(chan).view(np.int32)).to(self.device).reshape(1, ng, self.wpp)
+        tr = torch.empty((1, npos, 10), dtype=torch.int32, device=self.device)
+        darr, dptr = _lib.doped_array(self.doped)
+        check(lib().scldpc_stream_run_device_inputs_at(C.byref(p), 1, self.W, darr.size, dptr, int(npos),
+                                                       self.st.state.data_ptr(), self.st.counters.data_ptr(), tr.data_ptr(),
+                                                       d_inter.data_ptr(), d_chan.data_ptr(), int(g0), int(ng), int(self.done),
+                                                       _stream_ptr(self.st.state.device)))
+        rows = tr[0].cpu().numpy().astype(np.int64)
+        used = npos
+        if stop is not None:
+            for k in range(npos):
+                if stop(rows[k, 2:]):
+                    used = k + 1
+                    break
+        if used < npos:
+            # the reference generated L/2 + (positions decoded before the tripping one) positions at this point: rewind and
+            # draw exactly those
+            self._host[:] = snap
+            self._draw(dv - 1 if first else 0, g0, (half if first else 0) + used - 1)
+        elif stop is not None and stop(rows[npos - 1, 2:]):
+            self._host[:] = snap
+            self._draw(dv - 1 if first else 0, g0, (half if first else 0) + used - 1)
+        self.done += used
+        return rows[:used]
 
 
 class InputStreams(Streams):

@@ -203,6 +203,26 @@ int scldpc_full_bp_fixpoint_device_cn16(const scldpc_code_params *p, int32_t ntr
 int scldpc_full_bp_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
                                const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
                                int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+/* The same two decoders on the CN -> SOCKET table (scldpc_sample_philox_device_sock16 / scldpc_cn_sockets_device:
+ * position-local sockets s = dv*t + i, 0xFFFF = none), which lifts the n < 65535 limit of the global VN ids — e.g. the
+ * published L = 100, N = 1000 runs (n = 100 000).  Needs at most 65536 CNs per trial and 16-bit sockets. */
+int scldpc_full_bp_sock16_supported(const scldpc_code_params *p);
+int scldpc_full_bp_fixpoint_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                          const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t is_term,
+                                          int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+int scldpc_full_bp_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                 const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                                 int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
+/* decodeBP of the trajectory build (BPT:900-1140) on the same tables: the iterations WITH their rows — per iteration
+ * deg_1_iter, the VNs recovered and the position of the first erased VN (BPT:988, 1037-1038, 1051): d_rows int32
+ * [ntrials][rows_cap][3]; d_counters[SCLDPC_C_ITERATIONS] says how many rows a trial wrote (rows beyond rows_cap are dropped).
+ * is_term = 0: the truncated chain of `bp_traj … IS_TERM=0` (BPT:922-925, 944-948). */
+int scldpc_full_bp_traj_device_cn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                    const uint16_t *d_cn_adj16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                                    int32_t *d_counters, int32_t *d_rows, int32_t rows_cap, uint32_t *d_erased_bits, void *stream);
+int scldpc_full_bp_traj_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
+                                      const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
+                                      int32_t *d_counters, int32_t *d_rows, int32_t rows_cap, uint32_t *d_erased_bits, void *stream);
 
 /* decodeBP_SW, square window (BPW:628-912): window of W positions, init_it iterations for the
  * first window and max_it for the others (init_it == 0 ⇒ max_it, BPW:2101-2102). */
@@ -334,6 +354,23 @@ int scldpc_stream_run_device_inputs(const scldpc_code_params *p, int32_t nstream
                                     const int32_t *doped_positions, int32_t npos, void *d_state, int64_t *d_counters,
                                     int32_t *d_trace, const uint16_t *d_inter, const uint32_t *d_chan_bits,
                                     int32_t inputs_npos, int64_t positions_done, void *stream);
+/* The same for runs of any length, in pieces.  scldpc_stream_glibc_next_host continues from a carried state
+ * (scldpc_glibc_state_init = srandom(seed); scldpc_glibc_state_reset_perm = inizio_sim at the start of an ε point, BPF:1994;
+ * main_streaming seeds ONCE and carries random() from point to point, BPF:1942-1945): it shuffles `ninit` CN positions
+ * (initialize_arrays_circular: dv-1 at the start of a point, 0 afterwards), then draws generate_stream_pos(gpos0 + k),
+ * k < npos, into inter_out [ninit + npos][S] and chan_out [npos][wpp].  scldpc_stream_run_device_inputs_at is
+ * scldpc_stream_run_device_inputs with arrays that begin at generated position inputs_pos0 instead of 0: d_inter
+ * [nstreams][inputs_npos + dv - 1][S] holds CN positions inputs_pos0 .. inputs_pos0 + inputs_npos + dv - 2 (rows 0 .. dv-2 are
+ * read only by a stream's first call, when inputs_pos0 = 0), d_chan_bits [nstreams][inputs_npos][wpp] VN positions
+ * inputs_pos0 .. ; the call needs the generated positions L/2 + positions_done .. L/2 + positions_done + npos - 1 (and
+ * 0 .. L/2 - 1 on a stream's first call) to lie inside. */
+int scldpc_stream_glibc_next_host(const scldpc_code_params *p, void *state, double eps, int32_t ndoped,
+                                  const int32_t *doped_positions, int32_t ninit, int64_t gpos0, int32_t npos,
+                                  uint16_t *inter_out, uint32_t *chan_out);
+int scldpc_stream_run_device_inputs_at(const scldpc_code_params *p, int32_t nstreams, int32_t W, int32_t ndoped,
+                                       const int32_t *doped_positions, int32_t npos, void *d_state, int64_t *d_counters,
+                                       int32_t *d_trace, const uint16_t *d_inter, const uint32_t *d_chan_bits,
+                                       int64_t inputs_pos0, int32_t inputs_npos, int64_t positions_done, void *stream);
 
 /* plr_computation + willIstop over a batch, IN TRIAL ORDER (BPF:1503-1520, 440-451, 2140-2144):
  * adds the per-trial counters of trials 0..k into d_run[SCLDPC_NRUN] (int64, accumulated in place),

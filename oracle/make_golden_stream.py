@@ -23,12 +23,19 @@ SETS = [
     ("mid_e490_W12_dop101112", 50, 30, 150, 8, 0.49, 12, (10, 11, 12)),
     ("c5_e470_W20", 500, 50, 80, 1, 0.47, 20, ()),
     ("c5_e485_W20_dop101112", 500, 50, 100, 2, 0.485, 20, (10, 11, 12)),
+    # BASELINE config 5 at its own size, Def_M = 2500 (N = 5000): 64 decoded positions = 89 generated ones, so the circular
+    # buffer of L = 50 positions wraps around (about a minute of the reference each)
+    ("c5n5000_e480_W20", 2500, 50, 64, 11, 0.48, 20, ()),
+    ("c5n5000_e485_W20_dop101112", 2500, 50, 64, 12, 0.485, 20, (10, 11, 12)),
 ]
 
 
 def main():
     O.build(with_reference=True)
+    only = set(sys.argv[1:])                        # optional: regenerate just the named sets
     for name, M, L, P, seed, eps, W, doped in SETS:
+        if only and name not in only:
+            continue
         rows = O.run_ref_stream(M, L, P, seed, eps, W, doped, dump=(M <= 50))
         out = {"rows": np.array([[r[f] for f in O.Stream.FIELDS] for r in rows], dtype=np.int32),
                "meta": np.array(json.dumps(dict(name=name, Def_M=M, L=L, P=P, seed=seed, eps=eps, W=W, doped=list(doped),

@@ -55,6 +55,40 @@ def test_streaming_cli_writes_results_circular_rows(E, tmp_path):
     assert [ne, be, ee, bee, gb, gbl, gbe, gble] == tot.tolist()
 
 
+_RUNS = _json_runs = None
+
+
+def _whole_runs():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_wholeruns.json")))["runs"]
+
+
+@pytest.mark.parametrize("k", range(5))
+@pytest.mark.parametrize("chunk", [7, 64])
+def test_streaming_cli_replays_whole_reference_runs_row_for_row(E, tmp_path, k, chunk):
+    """`sw INDEX W NUM_DOPED … --rng glibc --seed S`: the reference's own experiment — ONE stream, one srandom(seed), the ε
+    points back to back with random() carried from point to point, each stopped where main_streaming stops (BPF:2033).
+    Fixtures: whole runs of the REAL reference (oracle/make_golden_stream_runs.py), N = 10 … 1000, with and without doping.
+    The chunk size (positions per launch) must not matter: a point that trips inside a chunk rewinds the host stream to
+    where the reference stopped drawing."""
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    r = _whole_runs()[k]
+    d = r["doped"]
+    B.streaming(["3", str(r["W"]), str(len(d)), *[str(x) for x in d], "--L", str(r["L"]), "--N", str(2 * r["Def_M"]),
+                 "--eps-ini", repr(r["eps_ini"]), "--eps-delta", repr(r["eps_delta"]), "--num-points", str(r["num_points"]),
+                 "--max-blocks-err", str(r["max_blocks_err"]), "--max-blocks", str(r["max_blocks"]), "--rng", "glibc",
+                 "--seed", str(r["seed"]), "--chunk", str(chunk), "--outdir", str(tmp_path), "--quiet"])
+    name = "SC_LDPC_4_8_L%d_M%d_DOP%d_BP_Stream_SW%d_Random_BLER_3.dat" % (r["L"], r["Def_M"], len(d), r["W"])
+    rows = open(tmp_path / name).read().strip().split("\n")
+    assert rows[0] == B.STREAM_HEADER.strip() and len(rows) == 1 + r["num_points"]
+    for row, ref in zip(rows[1:], r["rows"]):
+        f = row.split()
+        ne, be, ee, bee, gb, gbl, gbe, gble = ref["counters"]
+        assert [int(x) for x in f[5:]] == [ne, gb, be, gbl, ee, gbe, bee, gble], (f, ref)       # results_circular's order
+        assert f[0] == "%f" % ref["eps"]
+
+
 def test_streaming_rejects_windows_beyond_the_generated_stream(E):
     with pytest.raises(E.ScldpcError, match="L/2"):
         E.Streams(E.make_params(4, 8, 20, 10), 1, 1, 0.4, 9)

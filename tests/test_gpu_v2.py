@@ -49,6 +49,55 @@ def test_sampler_v2_equals_first_generation_and_twin(E, oracle, L, N, eps, doped
         _check_cn_table(E, p, A[t], CN[t])
 
 
+@pytest.mark.parametrize("L,N,eps,is_term,cap", [(100, 1000, 0.48, True, 0), (100, 1000, 0.47, False, 150), (50, 1000, 0.48, True, 60),
+                                                  (130, 800, 0.46, True, 0), (16, 200, 0.47, True, 5), (9, 24, 0.5, False, 0)])
+def test_small_decoder_on_the_socket_table_takes_long_chains(E, L, N, eps, is_term, cap):
+    """scldpc_full_bp(_fixpoint)_device_sock16: the 4-bits-per-CN decoder reading position-local sockets instead of global VN
+    ids, so that n >= 65535 (the published L = 100, N = 1000 runs: n = 100 000) no longer falls back to the 16-bit-word
+    kernels.  Every counter and the residual equal full_bp's (and, where both forms apply, the VN-id form's)."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    assert E.full_bp_sock16_supported(p) and (p.n < 65535) == E.cn16_supported(p)
+    T = 64
+    a, cs, ch = E.sample_philox_sock16(p, 31, 500, T, eps)
+    ref = E.full_bp(p, a, ch, max_it=cap, is_term=is_term, want_erased=True)
+    lvl = E.full_bp_cn16(p, a, cs, ch, max_it=cap, is_term=is_term, want_erased=True, sockets=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ref["counters"], lvl["counters"]) and torch.equal(ref["erased"], lvl["erased"])
+    if cap == 0:
+        fix = E.full_bp_fixpoint_cn16(p, a, cs, ch, is_term=is_term, want_erased=True, sockets=True)
+        assert (fix["counters"].cpu().numpy()[:, KEEP] == ref["counters"].cpu().numpy()[:, KEEP]).all()
+        assert torch.equal(ref["erased"], fix["erased"])
+    if E.cn16_supported(p):
+        a2, cn, ch2 = E.sample_philox_cn16(p, 31, 500, T, eps)
+        assert torch.equal(a, a2) and torch.equal(ch, ch2)
+        vn = E.full_bp_cn16(p, a2, cn, ch2, max_it=cap, is_term=is_term, want_erased=True)
+        assert torch.equal(vn["counters"], lvl["counters"])
+
+
+@pytest.mark.parametrize("L,N,which", [(50, 1000, -2), (9, 600, 3), (7, 2048, -2), (12, 1100, 11), (10, 10, -2)])
+def test_sampler_v2_exact_fallback_gives_the_same_tables(E, monkeypatch, L, N, which):
+    """A bucket count that does not fit its nibble, or more straddlers than the worklist holds, sends a CN position through
+    the exact fallback (rank of every key among all S, ties by socket) instead of trapping the process.  It never happens
+    on real draws, so the test forces it (SCLDPC_DEBUG_SAMPLER_EXACT_POS: one position, or -2 = every position): the
+    VN -> CN table must come out bit for bit, the CN -> VN / CN -> socket tables as the same sets."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    seed, t0, T = 99, 7, 3
+    a1, cn1, c1 = E.sample_philox_cn16(p, seed, t0, T, 0.48)
+    s1 = E.sample_philox_sock16(p, seed, t0, T, 0.48)[1]
+    monkeypatch.setenv("SCLDPC_DEBUG_SAMPLER_EXACT_POS", str(which))
+    a2, cn2, c2 = E.sample_philox_cn16(p, seed, t0, T, 0.48)
+    s2 = E.sample_philox_sock16(p, seed, t0, T, 0.48)[1]
+    torch.cuda.synchronize()
+    monkeypatch.delenv("SCLDPC_DEBUG_SAMPLER_EXACT_POS")
+    assert torch.equal(a1, a2) and torch.equal(c1, c2)
+    for x, y in ((cn1, cn2), (s1, s2)):
+        assert (np.sort(x.cpu().numpy().view(np.uint16), axis=2) == np.sort(y.cpu().numpy().view(np.uint16), axis=2)).all()
+    if which == -2:                                          # exact ranks: within a CN the sockets come in key order, not arrival order
+        _check_cn_table(E, p, a2[0].cpu().numpy(), cn2[0].cpu().numpy())
+
+
 @pytest.mark.parametrize("L,N,eps,is_term", [(50, 1000, 0.48, True), (50, 1000, 0.45, True), (50, 1000, 0.49, False),
                                              (16, 200, 0.47, True), (16, 200, 0.30, True), (9, 24, 0.5, False),
                                              (12, 1024, 0.46, True), (30, 400, 0.44, False), (10, 10, 0.48, True),
@@ -148,6 +197,37 @@ def test_level_decoder_on_reference_fixtures(E, name):
         assert (er == g["erased"][:T]).all()
     if g.has("rows"):
         assert [int(x) for x in c[:, 5]] == [len(g.rows_of(t)) for t in range(T)], name
+        # the trajectory build's rows (deg_1_iter, recovered, first erased position; BPT:988, 1051) from the same kernel,
+        # through both table forms (VN ids / sockets)
+        d_cs = E.cn_sockets(p, d_a)
+        for sockets, tab in ((False, d_cn), (True, d_cs)):
+            tr = E.full_bp_cn16(p, d_a, tab, d_ch, max_it=g.max_it, is_term=bool(m["is_term"]), rows_cap=2048, sockets=sockets)
+            torch.cuda.synchronize()
+            ct, rows = tr["counters"].cpu().numpy(), tr["rows"].cpu().numpy()
+            assert (ct == c).all()
+            for t in range(T):
+                ref = g.rows_of(t)
+                assert (rows[t, :len(ref)] == ref).all(), (name, sockets, t)
+
+
+@pytest.mark.parametrize("L,N,eps,is_term,cap", [(50, 1000, 0.48, True, 0), (50, 1000, 0.46, False, 0), (50, 1000, 0.47, True, 40),
+                                                  (100, 1000, 0.47, True, 0), (16, 200, 0.49, False, 9), (10, 10, 0.5, True, 0)])
+def test_trajectory_rows_of_the_level_kernel_equal_the_flooding_kernels(E, L, N, eps, is_term, cap):
+    """bp_traj's rows from full_bp_small (4-bit counts, six trials per CU) against full_bp's (16-bit CN words, two per CU) on
+    device-sampled trials: every row of every trial, the counters, truncated chains and binding caps included."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    T = 48
+    sockets = not E.cn16_supported(p)
+    a, tab, ch = (E.sample_philox_sock16 if sockets else E.sample_philox_cn16)(p, 5, 77, T, eps)
+    ref = E.full_bp(p, a, ch, max_it=cap, is_term=is_term, rows_cap=1024)
+    got = E.full_bp_cn16(p, a, tab, ch, max_it=cap, is_term=is_term, rows_cap=1024, sockets=sockets)
+    torch.cuda.synchronize()
+    c, r0, r1 = ref["counters"].cpu().numpy(), ref["rows"].cpu().numpy(), got["rows"].cpu().numpy()
+    assert (c == got["counters"].cpu().numpy()).all()
+    for t in range(T):
+        k = int(c[t, 5])
+        assert (r0[t, :k] == r1[t, :k]).all(), (t, np.argwhere(r0[t, :k] != r1[t, :k])[:3])
 
 
 def test_level_decoder_with_a_small_queue_takes_the_frontier_from_the_snapshot(E):

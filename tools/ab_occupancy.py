@@ -57,7 +57,8 @@ def decode(b=0):
 env()
 s0 = timeit(lambda k: sample(1), "sampler, default (2 WG/CU)")
 d0 = timeit(lambda k: decode(), "decoder, default (7 WG/CU)")
-ref = cnt.clone()
+KEEP = [0, 1, 2, 3, 4, 6, 7]                     # all but the barrier-round count (not an output of the reference)
+ref = cnt[:, KEEP].clone()
 print(f"serial step: {s0 + d0:.2f} ms -> {B / (s0 + d0) / 1e3:.3f} M trials/s", flush=True)
 
 # ---- 1. stand-alone at k workgroups per CU
@@ -68,7 +69,7 @@ for kcu in (6, 5, 4, 3, 2):
     env(LDS_PAD_DECODER=pad)
     cnt.zero_()
     timeit(lambda k: decode(), f"decoder, {kcu} WG/CU (LDS padded by {pad})")
-    assert torch.equal(cnt, ref)
+    assert torch.equal(cnt[:, KEEP], ref)
 
 # ---- 2. persistent launches, stand-alone and together
 for gs in (1, 2):
@@ -78,7 +79,7 @@ for gd in (4, 5, 6, 7):
     env(GRID_DECODER=gd * NCU)
     cnt.zero_()
     timeit(lambda k: decode(), f"decoder, persistent {gd} WG/CU")
-    assert torch.equal(cnt, ref)
+    assert torch.equal(cnt[:, KEEP], ref)
 
 s_a, s_b = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 env()
@@ -107,7 +108,7 @@ for gs, gd in ((1, 4), (1, 3), (1, 5), (2, 2), (2, 1)):
         env(GRID_SAMPLER=gs * NCU, GRID_DECODER=gd * NCU)
         cnt.zero_()
         ms = timeit(lambda k: both(k, order), f"persistent pair: {gs} sampler + {gd} decoders per CU, launch order {order}")
-        assert torch.equal(cnt, ref)
+        assert torch.equal(cnt[:, KEEP], ref)
         print(f"{'':40s}-> vs serial {s0 + d0:.2f} ms: x{(s0 + d0) / ms:.3f}", flush=True)
 env()
 cnt.zero_()
