@@ -392,6 +392,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
     const uint32_t t_lo = (uint32_t)trial, t_hi = (uint32_t)(trial >> 32);
     const int tr = blockIdx.x;
 
+    STAMP_DECL
     for (int b = tid; b < 2 * NB; b += kThreads) hist0[b] = 0;
     if (tid < 32) wsum[tid] = 0;
     __syncthreads();
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
     for (int p = 0; p <= a.D; p++) {
         uint32_t *hc = hist0 + (p & 1) * NB, *hp = hist0 + ((p & 1) ^ 1) * NB;
         const bool live = p < a.D;
+        STAMP(0);
         // ================================================ phase A ================================================
         if (p > 0) {
             // the worklist of p-1: true rank among the bucket mates (or, never in a real run, the exact fallback)
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                 else hp[tid] = 0u;
             }
         }
+        STAMP(1);                                                       // A: worklist of p-1 + clear
         if (live) {
             {   // the keys of p (threads without sockets hold zero keys and add zero); the round keys are recomputed by
                 // scalar adds rather than held in twenty SGPRs across the loop
@@ -481,7 +484,9 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
             }
             if (crowded & 16u) wsum[18 + (p & 1)] = 1u;                 // a bucket met its 16th key: its nibble wrapped
         }
+        STAMP(2);                                                       // A: keys + histogram
         __syncthreads();
+        STAMP(3);                                                       // barrier wait
         // ================================================ phase B ================================================
         if (tid == 0) { wsum[16] = 0; wsum[18 + ((p & 1) ^ 1)] = 0; }  // worklist count and the flag of p-1: consumed in phase A
         if (live) {
@@ -531,7 +536,9 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                 if (own) dst[tid] = src[tid];
             }
         }
+        STAMP(4);                                                       // B: scan + copy-out
         __syncthreads();
+        STAMP(5);                                                       // barrier wait
         // ================================================ phase C ================================================
         if (live && wsum[18 + (p & 1)] == 0u) {
             // exclusive prefix of the 16 wave totals, in lanes 0..15 of every wave; a key's wave is its top four bits
@@ -605,7 +612,9 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
             }
         }
         if constexpr (CNMODE == 1) ent0 += vV;                           // the VN of socket 0 moves one position on
+        STAMP(6);                                                       // C: classify
         __syncthreads();
+        STAMP(7);                                                       // barrier wait
     }
 
     // ---- channel: 32 VNs per output word, 8 Philox calls
@@ -629,6 +638,8 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
         }
         chan[w] = word;
     }
+    STAMP(8);                                                           // channel
+    STAMP_FLUSH();
 }
 
 int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t seed, uint64_t trial0, int32_t ntrials,
@@ -664,8 +675,11 @@ int launch_v2(const char *who, int cnmode, const scldpc_code_params *p, uint64_t
         if (c < x) c += 1.0;
         a.thresh = (uint32_t)c;
     }
-    // third generation (one Philox call per thread: at most 4096 sockets per position): two histogram buffers
-    const bool v3 = a.nb <= 4 * kThreads && !getenv("SCLDPC_DEBUG_SAMPLER_V2");
+    // Third generation (one Philox call per thread: at most 4096 sockets per position; two histogram buffers): measured equal to
+    // the second within +-4 % at N = 1000 (faster without the CN table and at N <= 512, slower with it: DESIGN.md §5), so
+    // it is opt-in (SCLDPC_SAMPLER_GEN=3) and the second generation stays the default.
+    const char *gen_env = getenv("SCLDPC_SAMPLER_GEN");
+    const bool v3 = a.nb <= 4 * kThreads && gen_env && atoi(gen_env) == 3;
     int off = ((v3 ? 2 : 1) * a.nb + 3) & ~3;
     a.off_gpk = off;   off += (a.S + 3) & ~3;
     a.off_fix = off;   off += (a.S / 2 + 3) & ~3;           // S uint16

@@ -17,17 +17,24 @@
 // position that entered it.  All per-stream state lives in a global-memory blob that persists between launches
 // (ring of L positions: 2-byte adjacency rows, S / VNerased bits, CN words, the last dv socket permutations,
 // counters); LDS holds the frontier queues, the bucket counters of the permutation ranking and per-slot counts.
+// Two kernels share the blob (round 3): GENERATE (1024 threads, the ranking's 71 KB of LDS: two streams per CU) draws a chunk
+// of positions ahead, DECODE (256 threads, 18 KB of LDS: eight streams per CU) then decodes as many — the window rounds are
+// waits on L2 / memory round trips, so four times the streams in flight per CU is what they want, while the ranking wants
+// the threads and the LDS.  Generating position g earlier than main_streaming does (it alternates decode / generate,
+// BPF:2015-2046) changes nothing the decoder can see: decodeBP_SW_circular(pos) touches positions pos-2dv+1 .. pos+W+dv-2
+// only, and a chunk is kept short enough that no ring slot still in use is overwritten.
 // Sampling is keyed like sampler.hip: permutation of CN position c = rank of the Philox words with counter
 // (socket>>2, c, stream id), channel of VN position q = counter (t>>2, 2^31 | q, stream id).
 #include "common.h"
 #include "kernel_util.h"
 #include "philox.h"
+#include <algorithm>
 
 namespace {
 
 using namespace scldpc_dev;
 
-constexpr int kThreads = 1024, kWaves = 16, kMaxDoped = 32, kMaxL = 256;
+constexpr int kGenThreads = 1024, kDecThreads = 256, kMaxDoped = 32, kMaxL = 256;
 constexpr int kQCap = 2048;                         // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
@@ -39,6 +46,7 @@ struct StateLayout {        // byte offsets inside one stream's blob
 
 struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
+    int gen_ahead;              // GEN: generate until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
@@ -53,7 +61,8 @@ struct Args {
     long long ext_pos0;         // first generated position the two arrays hold
     char *state;
     long long *counters_out;    // [nstreams][10]
-    int32_t *trace;             // optional [nstreams][npos][10]
+    int32_t *trace;             // optional [nstreams][trace_stride][10]; this launch writes rows trace_off .. trace_off + npos - 1
+    int trace_stride, trace_off;
 };
 
 using scldpc_dev::philox4x32_10;
@@ -70,17 +79,21 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
 // ROWS <= 4 (at most 4096 counter words, N <= 1024 at (4,8)): the LDS part is 34 KB, so two workgroups fit a CU if the
 // compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip) — the kernel waits on L2 round trips most of the time and a second
 // stream on the CU hides them.  Larger ensembles need the whole LDS for the counters and keep the registers they want.
-template <int ROWS>
+// GEN: this launch generates positions (up to a.gen_ahead beyond the decoder's position + L/2); DEC: it decodes a.npos
+// positions.  The product launches GEN-only (1024 threads) and DEC-only (256 threads) kernels in turn.
+template <int ROWS, bool GEN, bool DEC, int kThreads>
 __device__ __forceinline__ void stream_bp_body(const Args &a)
 {
+    constexpr int kWaves = kThreads / 64;
     extern __shared__ uint32_t lds[];
-    uint32_t *hist = lds;                                   // nb 16-bit bucket counters, two per word (ranking)
-    uint32_t *q0 = lds + a.nb / 2, *q1 = q0 + kQCap;        // frontier queues
+    // LDS: [queues | scan scratch | pos_cnt | scalars | totals] for both kernels; GEN adds [bucket counters | arrival slots]
+    uint32_t *q0 = lds, *q1 = q0 + kQCap;                   // frontier queues
     uint32_t *wsum = q1 + kQCap;                            // scan scratch
     int *pos_cnt = reinterpret_cast<int *>(wsum + 32);      // [L] erased VNs per ring slot
     int *scal = pos_cnt + kMaxL;
     long long *acc = reinterpret_cast<long long *>(scal + S_NSCAL);      // the eight running totals: thread 0's alone
-    uint8_t *tsl = reinterpret_cast<uint8_t *>(acc + 8);                 // [S] arrival slot of every socket's key in its bucket
+    uint32_t *hist = reinterpret_cast<uint32_t *>(acc + 8);             // nb 16-bit bucket counters, two per word (ranking)
+    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb / 2);         // [S] arrival slot of every socket's key in its bucket
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, ms = a.dv - 1, W = a.W, wpp = a.lay.wpp;
@@ -118,13 +131,15 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         // again; what a pass hands to the next lives in LDS (16-bit prefix per bucket, one byte of arrival slot per socket)
         // except the straddling buckets' keys, which are grouped in the stream's blob (3-15 % of the sockets).
         const int ncalls = (S + 3) / 4;
+        uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));          // (no Philox round keys hoisted out of the position loop and spilled)
         for (int b = tid; b < a.nb / 2; b += kThreads) hist[b] = 0;
         if (tid == 0) scal[S_WL] = 0;
         __syncthreads();
         uint32_t crowded = 0;
         for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
-            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int s = q * 4 + u;
@@ -192,7 +207,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         uint16_t *dst = inter + (size_t)(cpos % dv) * S;
         for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
-            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
             uint32_t c4[4] = {0, 0, 0, 0};                  // (a straddler's entry is written by the third pass)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -242,6 +257,8 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         const int slot = (int)(g % L), cslot_new = (int)((g + dv - 1) % L);
         for (int k = tid; k < C; k += kThreads) cn[cslot_new * C + k] = 0;      // a fresh CN position (BPF:1832-1837)
         const bool doped = position_is_doped(a, g);
+        uint32_t c_lo = a.seed_lo, c_hi = a.seed_hi;
+        asm volatile("" : "+s"(c_lo), "+s"(c_hi));
         int erased_here = 0;
         for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
             uint32_t word = 0;
@@ -251,7 +268,7 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
 #pragma unroll
                 for (int c8 = 0; c8 < 8; c8++) {
                     uint32_t r[4];
-                    philox4x32_10((uint32_t)(w * 8 + c8), 0x80000000u | (uint32_t)g, s_lo, s_hi, a.seed_lo, a.seed_hi, r);
+                    philox4x32_10((uint32_t)(w * 8 + c8), 0x80000000u | (uint32_t)g, s_lo, s_hi, c_lo, c_hi, r);
 #pragma unroll
                     for (int u = 0; u < 4; u++) word |= (uint32_t)((r[u] >> 1) < a.thresh) << (c8 * 4 + u);
                 }
@@ -280,17 +297,21 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         __syncthreads();
     };
 
-    if (gen == 0 && pos == 0) {                             // a new stream (BPF:2003-2012)
-        for (int i = tid; i < L * wpp; i += kThreads) { Sb[i] = 0; Eb[i] = 0; }
-        for (int i = tid; i < L * C; i += kThreads) cn[i] = 0;
-        for (int i = tid; i < L; i += kThreads) pos_cnt[i] = 0;
-        __syncthreads();
-        for (int c = 0; c < dv - 1; c++) rank_position(c);  // initialize_arrays_circular (BPF:1808-1813)
-        for (; gen < L / 2; gen++) generate(gen);
+    if constexpr (GEN) {
+        if (gen == 0 && pos == 0) {                         // a new stream (BPF:2003-2012)
+            for (int i = tid; i < L * wpp; i += kThreads) { Sb[i] = 0; Eb[i] = 0; }
+            for (int i = tid; i < L * C; i += kThreads) cn[i] = 0;
+            for (int i = tid; i < L; i += kThreads) pos_cnt[i] = 0;
+            __syncthreads();
+            for (int c = 0; c < dv - 1; c++) rank_position(c);  // initialize_arrays_circular (BPF:1808-1813)
+            for (; gen < L / 2; gen++) generate(gen);
+        }
+        if constexpr (!DEC)                                 // the positions the next DECODE launch will have consumed (BPF:2036-2045)
+            for (; gen < pos + L / 2 + a.gen_ahead; gen++) generate(gen);
     }
 
     int genq = 0;                                           // queue generation counter
-    for (int step = 0; step < a.npos; step++, pos++) {
+    for (int step = 0; DEC && step < a.npos; step++, pos++) {
         STAMP(0);
         const long long pd = pos - ms, pe = pos - 2 * dv + 1;
         if (tid == 0) {                                                         // BPF:2017-2028
@@ -413,14 +434,14 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             if (tid == 0 && cexp > 0) { acc[C_EE] += cexp; acc[C_BEE] += 1; }
         }
         if (a.trace && tid == 0) {
-            int32_t *tr = a.trace + ((size_t)blockIdx.x * a.npos + step) * 10;
+            int32_t *tr = a.trace + ((size_t)blockIdx.x * a.trace_stride + a.trace_off + step) * 10;
             tr[0] = (int32_t)pos; tr[1] = nep;
             tr[2] = (int32_t)acc[C_NE]; tr[3] = (int32_t)acc[C_BE]; tr[4] = (int32_t)acc[C_EE]; tr[5] = (int32_t)acc[C_BEE];
             tr[6] = (int32_t)acc[C_GB]; tr[7] = (int32_t)acc[C_GBL]; tr[8] = (int32_t)acc[C_GBE]; tr[9] = (int32_t)acc[C_GBLE];
         }
         __syncthreads();
         STAMP(3);
-        generate(gen); gen++;                                                      // BPF:2036-2045
+        if constexpr (GEN) { generate(gen); gen++; }                              // BPF:2036-2045 (one-kernel form)
         STAMP(6);
     }
     STAMP_FLUSH();
@@ -439,9 +460,14 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
 }
 
 template <int ROWS>
-__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_bp_kernel(const Args a)
+__global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_gen_kernel(const Args a)
 {
-    stream_bp_body<ROWS>(a);
+    stream_bp_body<ROWS, true, false, kGenThreads>(a);
+}
+
+__global__ __launch_bounds__(kDecThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void stream_dec_kernel(const Args a)
+{
+    stream_bp_body<1, false, true, kDecThreads>(a);
 }
 
 
@@ -524,14 +550,33 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     make_state_layout(p, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
     a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos; a.ext_pos0 = ext_pos0;
-    const int rows = a.nb / kThreads;
-    const size_t lds_bytes = 4u * ((size_t)a.nb / 2 + 2 * kQCap + 32 + kMaxL + S_NSCAL + 2 * 8) + (((size_t)a.S + 15) & ~(size_t)15);
-    if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_bytes);
-    void (*kern)(const Args) = rows == 1 ? stream_bp_kernel<1> : rows == 2 ? stream_bp_kernel<2>
-                               : rows == 4 ? stream_bp_kernel<4> : rows == 8 ? stream_bp_kernel<8> : stream_bp_kernel<16>;
-    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
-    hipLaunchKernelGGL(kern, dim3(nstreams), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
+    const int rows = a.nb / kGenThreads;
+    const size_t lds_dec = 4u * ((size_t)2 * kQCap + 32 + kMaxL + S_NSCAL + 2 * 8);
+    const size_t lds_gen = lds_dec + 4u * ((size_t)a.nb / 2) + (((size_t)a.S + 15) & ~(size_t)15);
+    if (lds_gen > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_gen);
+    void (*gen_kern)(const Args) = rows == 1 ? stream_gen_kernel<1> : rows == 2 ? stream_gen_kernel<2>
+                                   : rows == 4 ? stream_gen_kernel<4> : rows == 8 ? stream_gen_kernel<8> : stream_gen_kernel<16>;
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(gen_kern))) return rc_;
+    // Cycles of GENERATE (run `ahead` positions beyond the reference's lag of L/2) and DECODE (as many positions as are
+    // then generated far enough: decodeBP_SW_circular(pos) needs positions up to pos + W + dv - 2).  `ahead` is bounded by the
+    // ring: generating position g re-uses the slots of VN position g - L and CN position g + dv - 1 - L, and the decoder
+    // still reads CN position pos - 2dv + 1 (expurgation): ahead <= ceil(L/2) - 3dv + 2.  The call ends as main_streaming
+    // leaves a stream: generated = decoded + L/2.
+    const int half = p->L / 2, ahead_max = std::max(0, (p->L - half) - 3 * p->dv + 2);
+    const hipStream_t hs = static_cast<hipStream_t>(stream);
+    a.trace_stride = npos;
+    for (int done = 0; done < npos;) {
+        const int ahead = std::min(ahead_max, npos - done);
+        const int c = std::min(npos - done, ahead + half - W - p->dv + 2);
+        a.gen_ahead = ahead; a.npos = 0;
+        hipLaunchKernelGGL(gen_kern, dim3(nstreams), dim3(kGenThreads), lds_gen, hs, a);
+        a.npos = c; a.trace_off = done;
+        hipLaunchKernelGGL(stream_dec_kernel, dim3(nstreams), dim3(kDecThreads), lds_dec, hs, a);
+        done += c;
+    }
+    a.gen_ahead = 0; a.npos = 0;                                    // a new stream's first L/2 positions, or catching up
+    hipLaunchKernelGGL(gen_kern, dim3(nstreams), dim3(kGenThreads), lds_gen, hs, a);
     SCLDPC_HIP_CHECK(hipGetLastError());
     return SCLDPC_OK;
 }

@@ -31,8 +31,10 @@ def _check_cn_table(E, p, adj16, cn16):
                                            (5, 128, 1.0, (0,)), (16, 512, 0.5, ()), (9, 600, 0.47, ()),
                                            # more than 4096 sockets per position: two Philox calls per thread
                                            (7, 2048, 0.47, (2,)), (12, 1100, 0.5, ()), (15, 2000, 0.48, ()), (6, 1028, 0.4, ())])
-def test_sampler_v2_equals_first_generation_and_twin(E, oracle, L, N, eps, doped):
+def test_sampler_v2_equals_first_generation_and_twin(E, oracle, L, N, eps, doped, monkeypatch):
     import torch
+    if (L + N) % 2:                                          # every other case through the opt-in third-generation kernel
+        monkeypatch.setenv("SCLDPC_SAMPLER_GEN", "3")
     p = E.make_params(4, 8, L, N)
     assert E.cn16_supported(p)
     po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
@@ -75,8 +77,9 @@ def test_small_decoder_on_the_socket_table_takes_long_chains(E, L, N, eps, is_te
         assert torch.equal(vn["counters"], lvl["counters"])
 
 
+@pytest.mark.parametrize("gen", ["2", "3"])
 @pytest.mark.parametrize("L,N,which", [(50, 1000, -2), (9, 600, 3), (7, 2048, -2), (12, 1100, 11), (10, 10, -2)])
-def test_sampler_v2_exact_fallback_gives_the_same_tables(E, monkeypatch, L, N, which):
+def test_sampler_v2_exact_fallback_gives_the_same_tables(E, monkeypatch, L, N, which, gen):
     """A bucket count that does not fit its nibble, or more straddlers than the worklist holds, sends a CN position through
     the exact fallback (rank of every key among all S, ties by socket) instead of trapping the process.  It never happens
     on real draws, so the test forces it (SCLDPC_DEBUG_SAMPLER_EXACT_POS: one position, or -2 = every position): the
@@ -84,8 +87,10 @@ def test_sampler_v2_exact_fallback_gives_the_same_tables(E, monkeypatch, L, N, w
     import torch
     p = E.make_params(4, 8, L, N)
     seed, t0, T = 99, 7, 3
+    monkeypatch.setenv("SCLDPC_SAMPLER_GEN", "2")           # the default kernels give the tables to compare with
     a1, cn1, c1 = E.sample_philox_cn16(p, seed, t0, T, 0.48)
     s1 = E.sample_philox_sock16(p, seed, t0, T, 0.48)[1]
+    monkeypatch.setenv("SCLDPC_SAMPLER_GEN", gen)           # (the third generation takes N <= 1024; beyond, the second runs)
     monkeypatch.setenv("SCLDPC_DEBUG_SAMPLER_EXACT_POS", str(which))
     a2, cn2, c2 = E.sample_philox_cn16(p, seed, t0, T, 0.48)
     s2 = E.sample_philox_sock16(p, seed, t0, T, 0.48)[1]

@@ -24,10 +24,7 @@ cnt = torch.empty((B, 8), dtype=torch.int32, device=dev)
 
 
 def gen(v2):
-    if v2:
-        os.environ["SCLDPC_DEBUG_SAMPLER_V2"] = "1"
-    else:
-        os.environ.pop("SCLDPC_DEBUG_SAMPLER_V2", None)
+    os.environ["SCLDPC_SAMPLER_GEN"] = "2" if v2 else "3"
 
 
 def timeit(fn, name):

@@ -39,8 +39,13 @@ show("full_bp_kernel", ["clear+channel", "build", "release", "wave reductions", 
                         "final+expurgation"])
 out2 = E.full_bp_fixpoint(p, d_adj, d_ch)
 show("full_bp_fixpoint_kernel", ["channel+build", "peeling (rounds + barrier-free phase)", "final+expurgation"])
+os.environ["SCLDPC_SAMPLER_GEN"] = "2"
 a2, cn2, ch2 = E.sample_philox_cn16(p, 1, 0, T, 0.48)
 show("sample_philox_v2_kernel", ["emit(prev)", "keys+histogram", "scan", "classify", "rank+stage+clear", "emit", "channel"])
+os.environ["SCLDPC_SAMPLER_GEN"] = "3"
+a2, cn2, ch2 = E.sample_philox_cn16(p, 1, 0, T, 0.48)
+show("sample_philox_v3_kernel", ["(loop top)", "A: worklist of p-1 + clear", "A: keys + histogram", "barrier wait A", "B: scan + copy-out",
+                                 "barrier wait B", "C: classify", "barrier wait C", "channel"])
 out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
 if "--stream" in sys.argv:                      # BASELINE config 5: where does a decoded position's time go?
