@@ -8,7 +8,7 @@
 extern __device__ long long *g_scldpc_stamps;          // [block][16] cycle sums, written by lane 0 of wave 0
 #define STAMP_DECL long long st_acc[16] = {0}; long long st_last = (long long)__builtin_amdgcn_s_memtime();
 #define STAMP(k) do { if (threadIdx.x == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } } while (0)
-#define STAMP_FLUSH() do { if (threadIdx.x == 0 && g_scldpc_stamps) for (int k_ = 0; k_ < 16; k_++) g_scldpc_stamps[(size_t)blockIdx.x * 16 + k_] = st_acc[k_]; } while (0)
+#define STAMP_FLUSH() do { if (threadIdx.x == 0 && g_scldpc_stamps) for (int k_ = 0; k_ < 16; k_++) g_scldpc_stamps[(size_t)blockIdx.x * 16 + k_] += st_acc[k_]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(k) do {} while (0)

@@ -441,7 +441,12 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
             for (int t = tid; t < a.vns_pos; t += kThreads) {
                 const size_t j = (size_t)blockIdx.x * a.n + (size_t)qpos * a.vns_pos + t;
                 uint32_t l[8];
-                for (int i = 0; i < dv; i++) l[i] = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                if (dv == 4) {                              // four independent loads in flight (a run-time dv loop serialises them)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) l[i] = win[(size_t)((qpos + i) & 3) * S + 4 * t + i];
+                } else {
+                    for (int i = 0; i < dv; i++) l[i] = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                }
                 if (ADJ16 && dv == 4) {
                     *reinterpret_cast<uint2 *>(a.vn_adj16 + j * 4) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
                 } else {

@@ -1,4 +1,4 @@
-// Streaming (circular-buffer) window decoding of a doped SC-LDPC stream — gfx950 kernel.
+// Streaming (circular-buffer) window decoding of a doped SC-LDPC stream — gfx950 kernels.
 //
 // Replaces the body of main_streaming (BPF:1934-2054; BPF = simulators_sc_ldpc/bp_decoding/
 // SC_LDPC_Simulator_BPDecoder_BEC_full_BP_LimIter_OlmosRandomEnsemble.c, a mode the shipped source compiles out
@@ -9,20 +9,28 @@
 //                                     size-2 stopping-set expurgation of position pos-2dv+1),
 //     generate_stream_pos(gen_pos++) (BPF:1927-1932: shuffle CN position gen_pos+dv-1, wire VN position gen_pos,
 //                                     draw its channel unless it is doped, reset its messages).
-// One workgroup = one independent stream; the unit of work is one decoded position.  Same node-level machine as
-// sw_bp.hip: S = what the CNs see, one [cnt | Σ id] word per CN slot kept exact, only CNs of the
-// window fire (CNs to the right have never been updated and send erasures; CNs to the left are frozen and, with
-// exact counts, have nothing left to say), every VN a window CN is left with lies inside the VN window.  A window
-// reaches its fixpoint before the next one opens, so the frontier of a new window is just the degree-1 CNs of the
-// position that entered it.  All per-stream state lives in a global-memory blob that persists between launches
-// (ring of L positions: 2-byte adjacency rows, S / VNerased bits, CN words, the last dv socket permutations,
-// counters); LDS holds the frontier queues, the bucket counters of the permutation ranking and per-slot counts.
-// Two kernels share the blob (round 3): GENERATE (1024 threads, the ranking's 71 KB of LDS: two streams per CU) draws a chunk
-// of positions ahead, DECODE (256 threads, 18 KB of LDS: eight streams per CU) then decodes as many — the window rounds are
-// waits on L2 / memory round trips, so four times the streams in flight per CU is what they want, while the ranking wants
-// the threads and the LDS.  Generating position g earlier than main_streaming does (it alternates decode / generate,
-// BPF:2015-2046) changes nothing the decoder can see: decodeBP_SW_circular(pos) touches positions pos-2dv+1 .. pos+W+dv-2
-// only, and a chunk is kept short enough that no ring slot still in use is overwritten.
+// One workgroup = one independent stream; the unit of work is one decoded position.  Two kernels share a stream's blob:
+//
+//  * GENERATE (1024 threads, the ranking's LDS: two streams per CU) draws a chunk of positions ahead: the socket permutation
+//    of a CN position by ranking Philox keys (as sampler.hip), the VN -> CN rows of a VN position, its channel bits, and —
+//    round 3 — the CN -> socket rows of the CN position (every CN's dc sockets s = dv*t + i = edge i of VN t of position
+//    CNpos - i), staged in the LDS the ranking has finished with and written out whole.
+//  * DECODE (256 threads) keeps the window's state — and nothing else — in LDS, as sw_ring.hip does for the square window:
+//    4-bit CN counts of positions [pos-2dv+1, pos+W+dv-2] and the S bits (what the CNs still see as erased) of VN positions
+//    [pos-2dv+1, pos+W-1].  A VN position ENTERS when the window first reaches it (its channel bits are read, its erased VNs
+//    count themselves into their dv CN positions); a CN whose count is one finds its lone erased neighbour in its
+//    CN -> socket row as the socket whose S bit is still set.  Until round 3 the CN state ([cnt | sum of ids] words), the S
+//    bits and the per-position counts lived in the blob and every release made six round trips to the L2 / memory (row,
+//    S-bit claim, dv returning atomics): 14 500 requests per decoded position at N = 5000, 40 G requests/s over 2048
+//    streams — the memory system's random-request ceiling, not latency, was the bound (profiles/r03_stream_*.txt).  Now a
+//    release makes two (CN row, VN row), all atomics are LDS atomics, and generation makes none.
+//
+// Generating position g earlier than main_streaming does (it alternates decode / generate, BPF:2015-2046) changes nothing the
+// decoder can see: decodeBP_SW_circular(pos) touches positions pos-2dv+1 .. pos+W+dv-2 only, and a chunk is kept short
+// enough that no ring slot still in use is overwritten.  Window semantics: only CNs of the window fire
+// (CNs to the right have never been updated and send erasures; CNs to the left are frozen and, with exact counts, have
+// nothing left to say), every VN a window CN is left with lies inside the VN window.  A window reaches its fixpoint before
+// the next one opens, so the frontier of a new window is just the degree-1 CNs of the CN position that entered it.
 // Sampling is keyed like sampler.hip: permutation of CN position c = rank of the Philox words with counter
 // (socket>>2, c, stream id), channel of VN position q = counter (t>>2, 2^31 | q, stream id).
 #include "common.h"
@@ -40,13 +48,15 @@ enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
-    size_t adj, inter, sbits, ebits, cn, poscnt, gkey, wlist, counters, total;
-    int wpp;                // 32-bit words of S / VNerased per position
+    size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, poscnt, gkey, wlist, counters, total;
+    int wpp;                // 32-bit words of S bits per position
+    int Cw;                 // 32-bit words of count nibbles per CN position
+    int R, RV;              // ring slots: CN positions / VN positions the decoder keeps in LDS
 };
 
 struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
-    int gen_ahead;              // GEN: generate until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
+    int gen_ahead;              // GENERATE: until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
@@ -76,47 +86,37 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
     return false;
 }
 
+// =================================================== GENERATE ============================================================
 // ROWS <= 4 (at most 4096 counter words, N <= 1024 at (4,8)): the LDS part is 34 KB, so two workgroups fit a CU if the
-// compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip) — the kernel waits on L2 round trips most of the time and a second
-// stream on the CU hides them.  Larger ensembles need the whole LDS for the counters and keep the registers they want.
-// GEN: this launch generates positions (up to a.gen_ahead beyond the decoder's position + L/2); DEC: it decodes a.npos
-// positions.  The product launches GEN-only (1024 threads) and DEC-only (256 threads) kernels in turn.
-template <int ROWS, bool GEN, bool DEC, int kThreads>
-__device__ __forceinline__ void stream_bp_body(const Args &a)
+// compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip).  Larger ensembles need more LDS for the counters.
+template <int ROWS>
+__device__ __forceinline__ void stream_gen_body(const Args &a)
 {
-    constexpr int kWaves = kThreads / 64;
+    constexpr int kThreads = kGenThreads, kWaves = kThreads / 64;
     extern __shared__ uint32_t lds[];
-    // LDS: [queues | scan scratch | pos_cnt | scalars | totals] for both kernels; GEN adds [bucket counters | arrival slots]
-    uint32_t *q0 = lds, *q1 = q0 + kQCap;                   // frontier queues
-    uint32_t *wsum = q1 + kQCap;                            // scan scratch
-    int *pos_cnt = reinterpret_cast<int *>(wsum + 32);      // [L] erased VNs per ring slot
-    int *scal = pos_cnt + kMaxL;
-    long long *acc = reinterpret_cast<long long *>(scal + S_NSCAL);      // the eight running totals: thread 0's alone
-    uint32_t *hist = reinterpret_cast<uint32_t *>(acc + 8);             // nb 16-bit bucket counters, two per word (ranking)
-    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb / 2);         // [S] arrival slot of every socket's key in its bucket
+    uint32_t *wsum = lds;                                               // scan scratch
+    int *scal = reinterpret_cast<int *>(wsum + 32);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // nb 16-bit bucket counters, two per word (ranking); then the CN-row stage
+    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb / 2);         // [S] arrival slot of every socket's key in its bucket; then the CN fill counters
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, ms = a.dv - 1, W = a.W, wpp = a.lay.wpp;
+    const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, wpp = a.lay.wpp;
     char *st = a.state + (size_t)blockIdx.x * a.lay.total;
     uint16_t *adj = reinterpret_cast<uint16_t *>(st + a.lay.adj);          // [L][V][dv] position-local CN ids
+    uint16_t *cnsock = reinterpret_cast<uint16_t *>(st + a.lay.cnsock);    // [L][C][dc] sockets of every CN
     uint16_t *inter = reinterpret_cast<uint16_t *>(st + a.lay.inter);      // [dv][S] CN-local id of socket, by CN position % dv
-    uint32_t *Sb = reinterpret_cast<uint32_t *>(st + a.lay.sbits);         // [L][wpp]
-    uint32_t *Eb = reinterpret_cast<uint32_t *>(st + a.lay.ebits);         // [L][wpp] VNerased
-    uint32_t *cn = reinterpret_cast<uint32_t *>(st + a.lay.cn);            // [L*C]
-    int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
+    uint32_t *Sb = reinterpret_cast<uint32_t *>(st + a.lay.sbits);         // [L][wpp] channel bits of generated positions
     uint2 *gkey = reinterpret_cast<uint2 *>(st + a.lay.gkey);             // [S] (key, socket) of straddling buckets' keys, by rank slot
     uint2 *wlist = reinterpret_cast<uint2 *>(st + a.lay.wlist);           // [S] the same keys as a dense list: (key, socket | first rank << 16)
     long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
     const unsigned long long sid = a.sid0 + blockIdx.x;
     const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
-    auto ldcn = [&](int c) { return __hip_atomic_load(&cn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
     STAMP_DECL
-    for (int i = tid; i < L; i += kThreads) pos_cnt[i] = pos_cnt_g[i];
     if (tid < S_NSCAL) scal[tid] = 0;
     __syncthreads();
-    if (tid == 0) for (int k = C_NE; k <= C_GBLE; k++) acc[k] = cnt64[k];
-    long long pos = cnt64[C_POS], gen = cnt64[C_GEN];
+    const long long pos = cnt64[C_POS];
+    long long gen = cnt64[C_GEN];
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
     auto rank_position = [&](long long cpos) {
@@ -250,16 +250,49 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         __syncthreads();
     };
 
-    // ---- generate_stream_pos(g) + initialize_messages_circular(g) (BPF:1927-1932, 1149-1166) ------------------
+
+    // ---- the CN -> socket rows of CN position cpos from its finished socket -> CN row: the ranking's LDS is free now, so
+    //      the rows are staged there (a nibble-wide fill counter per CN hands out the dc places of a row: which place a
+    //      socket gets is immaterial, consumers treat a row as a set) and written out whole, `chunk` CNs at a time -------
+    auto cn_rows = [&](long long cpos) {
+        const uint16_t *row = inter + (size_t)(cpos % dv) * S;
+        uint16_t *stage = reinterpret_cast<uint16_t *>(hist);
+        uint32_t *fill = reinterpret_cast<uint32_t *>(tsl);
+        const int chunk = std::min(C, (a.nb / a.dc) & ~7);                // CNs per pass: the stage holds a.nb sockets (2 bytes each)
+        uint16_t *dst = cnsock + (size_t)(cpos % L) * C * a.dc;
+        for (int c0 = 0; c0 < C; c0 += chunk) {
+            const int c1 = std::min(C, c0 + chunk);
+            for (int w = tid; w < (chunk + 7) / 8; w += kThreads) fill[w] = 0;
+            __syncthreads();
+            for (int s = tid; s < S; s += kThreads) {
+                const int c = (int)row[s] - c0;
+                if ((unsigned)c < (unsigned)(c1 - c0)) {
+                    const uint32_t sh = (uint32_t)(c & 7) * 4u;
+                    const uint32_t k = (atomicAdd(&fill[c >> 3], 1u << sh) >> sh) & 15u;
+                    stage[c * a.dc + (int)k] = (uint16_t)s;
+                }
+            }
+            __syncthreads();
+            if ((a.dc & 1) == 0) {
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + (size_t)c0 * a.dc);
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage);
+                for (int w = tid; w < (c1 - c0) * a.dc / 2; w += kThreads) d32[w] = s32[w];
+            } else {
+                for (int w = tid; w < (c1 - c0) * a.dc; w += kThreads) dst[(size_t)c0 * a.dc + w] = stage[w];
+            }
+            __syncthreads();
+        }
+    };
+
+    // ---- generate_stream_pos(g) (BPF:1927-1932): CN position g+dv-1 ranked, VN position g wired, its channel drawn ----------
     auto generate = [&](long long g) {
         rank_position(g + dv - 1);
         STAMP(4);
-        const int slot = (int)(g % L), cslot_new = (int)((g + dv - 1) % L);
-        for (int k = tid; k < C; k += kThreads) cn[cslot_new * C + k] = 0;      // a fresh CN position (BPF:1832-1837)
+        cn_rows(g + dv - 1);
+        const int slot = (int)(g % L);
         const bool doped = position_is_doped(a, g);
         uint32_t c_lo = a.seed_lo, c_hi = a.seed_hi;
         asm volatile("" : "+s"(c_lo), "+s"(c_hi));
-        int erased_here = 0;
         for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
             uint32_t word = 0;
             if (a.ext_chan) {
@@ -275,63 +308,180 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
                 if (w * 32 + 32 > V) word &= (1u << (V - w * 32)) - 1u;
             }
             Sb[slot * wpp + w] = word;
-            erased_here += __popc(word);
         }
-        {
-            const uint32_t tot = wave_inclusive_scan((uint32_t)erased_here);
-            if (lane == 63 && tot) atomicAdd(&scal[S_ACC], (int)tot);
+        STAMP(5);
+        for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
+            if (dv == 4) {                                  // four independent loads, one 8-byte row store
+                uint32_t loc[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) loc[i] = inter[(size_t)((g + i) & 3) * S + 4 * t + i];
+                *reinterpret_cast<uint2 *>(adj + ((size_t)slot * V + t) * 4) = make_uint2(loc[0] | (loc[1] << 16), loc[2] | (loc[3] << 16));
+            } else {
+                for (int i = 0; i < dv; i++) adj[((size_t)slot * V + t) * dv + i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
+            }
         }
         __syncthreads();
-        STAMP(5);
-        if (tid == 0) { pos_cnt[slot] = scal[S_ACC]; scal[S_ACC] = 0; }
-        for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
-            uint16_t loc[8];
-            for (int i = 0; i < dv; i++) {
-                loc[i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
-                adj[((size_t)slot * V + t) * dv + i] = loc[i];
+        STAMP(6);
+    };
+
+    if (gen == 0 && pos == 0) {                             // a new stream (BPF:2003-2012)
+        for (int c = 0; c < dv - 1; c++) { rank_position(c); cn_rows(c); }       // initialize_arrays_circular (BPF:1808-1813)
+        for (; gen < L / 2; gen++) generate(gen);
+    }
+    for (; gen < pos + L / 2 + a.gen_ahead; gen++) generate(gen);   // what the next DECODE launches will have consumed (BPF:2036-2045)
+    STAMP_FLUSH();
+    if (tid == 0) {
+        cnt64[C_GEN] = gen;
+        if (a.counters_out) a.counters_out[(size_t)blockIdx.x * 10 + 9] = gen;
+    }
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_gen_kernel(const Args a)
+{
+    stream_gen_body<ROWS>(a);
+}
+
+// ==================================================== DECODE =============================================================
+// 256 threads per stream; the window's state in LDS (sw_ring.hip's layout, here for the classical window on a circular
+// buffer with unlimited iterations per position).  Ring slots are addressed relative to the decoder's position: every
+// position touched while it stands at `pos` lies within [pos - 2dv + 1, pos + W + dv - 2], less than a ring apart.
+template <int DV>
+__device__ __forceinline__ void stream_dec_body(const Args &a)
+{
+    constexpr int kThreads = kDecThreads;
+    extern __shared__ uint32_t lds[];
+    const int L = a.L, C = a.C, V = a.V, W = a.W, wpp = a.lay.wpp, Cw = a.lay.Cw, R = a.lay.R, RV = a.lay.RV, dc = a.dc;
+    constexpr int ms = DV - 1;
+    long long *acc = reinterpret_cast<long long *>(lds);                // the eight running totals: thread 0's alone
+    uint32_t *cnt = lds + 16;                                           // [R][Cw] words of 8 count nibbles
+    uint32_t *Sr = cnt + R * Cw;                                        // [RV][wpp] S bits
+    uint32_t *q0 = Sr + RV * wpp, *q1 = q0 + kQCap;                     // frontier queues: [CN position offset + 2dv | CN]
+    int *pos_cnt = reinterpret_cast<int *>(q1 + kQCap);                 // [L] erased VNs per buffer slot (position % L)
+    int *scal = pos_cnt + kMaxL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    char *st = a.state + (size_t)blockIdx.x * a.lay.total;
+    const uint16_t *adj = reinterpret_cast<const uint16_t *>(st + a.lay.adj);
+    const uint16_t *cnsock = reinterpret_cast<const uint16_t *>(st + a.lay.cnsock);
+    const uint32_t *Sb = reinterpret_cast<const uint32_t *>(st + a.lay.sbits);
+    uint32_t *ring_cnt = reinterpret_cast<uint32_t *>(st + a.lay.ring_cnt);
+    uint32_t *ring_s = reinterpret_cast<uint32_t *>(st + a.lay.ring_s);
+    int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
+    long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
+
+    STAMP_DECL
+    long long pos = cnt64[C_POS];
+    // ---- the rings and the per-slot counts come from the blob (zero for a new stream) ------------------------------------
+    if (pos == 0) {
+        for (int i = tid; i < R * Cw + RV * wpp; i += kThreads) cnt[i] = 0;        // (Sr follows cnt)
+        for (int i = tid; i < L; i += kThreads) pos_cnt[i] = 0;
+    } else {
+        for (int i = tid; i < R * Cw; i += kThreads) cnt[i] = ring_cnt[i];
+        for (int i = tid; i < RV * wpp; i += kThreads) Sr[i] = ring_s[i];
+        for (int i = tid; i < L; i += kThreads) pos_cnt[i] = pos_cnt_g[i];
+    }
+    if (tid < S_NSCAL) scal[tid] = 0;
+    if (tid == 0) for (int k = C_NE; k <= C_GBLE; k++) acc[k] = cnt64[k];
+    __syncthreads();
+
+    // slot of a position in a ring of n slots (p may be negative near the start of a stream: those positions hold nothing)
+    auto slot_of = [](long long p, int n) { int r = (int)(p % n); return r < 0 ? r + n : r; };
+    int cb = slot_of(pos, R), vb = slot_of(pos, RV), lb = slot_of(pos, L);           // slots of the decoder's own position
+    auto cslot = [&](int d) {                                           // word base of CN position pos + d
+        int sl = cb + d;
+        sl -= sl >= R ? R : 0;
+        sl += sl < 0 ? R : 0;
+        return sl * Cw;
+    };
+    auto sslot = [&](int d) {                                           // word base of the S bits of VN position pos + d
+        int sl = vb + d;
+        sl -= sl >= RV ? RV : 0;
+        sl += sl < 0 ? RV : 0;
+        return sl * wpp;
+    };
+    auto lslot = [&](int d) {                                           // buffer slot (position % L) of position pos + d
+        int sl = lb + d;
+        sl -= sl >= L ? L : 0;
+        sl += sl < 0 ? L : 0;
+        return sl;
+    };
+
+    // ---- VN position pos + d enters the ring: channel bits, per-position count, its erased VNs into their CN positions.
+    //      Its right-most CN position is a fresh slot. ----------------------------------------------------------------------
+    auto enter = [&](int d) {
+        for (int i = tid; i < Cw; i += kThreads) cnt[cslot(d + DV - 1) + i] = 0;
+        const int ls = lslot(d), sb = sslot(d);
+        int mine = 0;
+        for (int w = tid; w < wpp; w += kThreads) {
+            const uint32_t x = Sb[ls * wpp + w];
+            Sr[sb + w] = x;
+            mine += __popc(x);
+        }
+        mine = wave_sum(mine);
+        if (tid == 0) pos_cnt[ls] = 0;
+        __syncthreads();
+        if (lane == 0 && mine) atomicAdd(&pos_cnt[ls], mine);
+        // rows are loaded unconditionally, four per thread in flight (coalesced 8-byte loads), then the erased ones count
+        const uint2 *vrow = reinterpret_cast<const uint2 *>(adj) + (size_t)ls * V;
+        for (int t0 = tid; t0 < V; t0 += 4 * kThreads) {
+            uint2 r[4];
+            bool er[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u * kThreads;
+                er[u] = false;
+                if (t < V) { r[u] = vrow[t]; er[u] = (Sr[sb + (t >> 5)] >> (t & 31)) & 1u; }
             }
-            if ((Sb[slot * wpp + (t >> 5)] >> (t & 31)) & 1u)
-                for (int i = 0; i < dv; i++)
-                    atomicAdd(&cn[(int)((g + i) % L) * C + loc[i]], kCntOne + (uint32_t)(slot * V + t));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!er[u]) continue;
+                const uint32_t l[4] = {r[u].x & 0xFFFFu, r[u].x >> 16, r[u].y & 0xFFFFu, r[u].y >> 16};
+#pragma unroll
+                for (int i = 0; i < DV; i++) atomicAdd(&cnt[cslot(d + i) + (l[i] >> 3)], 1u << ((l[i] & 7) * 4));
+            }
         }
         __syncthreads();
     };
 
-    if constexpr (GEN) {
-        if (gen == 0 && pos == 0) {                         // a new stream (BPF:2003-2012)
-            for (int i = tid; i < L * wpp; i += kThreads) { Sb[i] = 0; Eb[i] = 0; }
-            for (int i = tid; i < L * C; i += kThreads) cn[i] = 0;
-            for (int i = tid; i < L; i += kThreads) pos_cnt[i] = 0;
-            __syncthreads();
-            for (int c = 0; c < dv - 1; c++) rank_position(c);  // initialize_arrays_circular (BPF:1808-1813)
-            for (; gen < L / 2; gen++) generate(gen);
-        }
-        if constexpr (!DEC)                                 // the positions the next DECODE launch will have consumed (BPF:2036-2045)
-            for (; gen < pos + L / 2 + a.gen_ahead; gen++) generate(gen);
-    }
-
     int genq = 0;                                           // queue generation counter
-    for (int step = 0; DEC && step < a.npos; step++, pos++) {
+    for (int step = 0; step < a.npos; step++, pos++) {
         STAMP(0);
-        const long long pd = pos - ms, pe = pos - 2 * dv + 1;
+        const long long pd = pos - ms, pe = pos - 2 * DV + 1;
         if (tid == 0) {                                                         // BPF:2017-2028
             if (pd >= 0 && !position_is_doped(a, pd)) { acc[C_GB] += V; acc[C_GBL] += 1; }
             if (pe >= 0 && !position_is_doped(a, pe)) { acc[C_GBE] += V; acc[C_GBLE] += 1; }
         }
+        // the VN window [pos - ms, pos + W) takes in position pos + W - 1 (a new stream: positions 0 .. W-1)
+        for (int d = (pos == 0 ? 0 : W - 1); d < W; d++) enter(d);
 
-        // ---- decodeBP_SW_circular(pos) --------------------------------------------------------------------
-        // frontier of a new window: degree-1 CNs of the position(s) that entered it
+        // ---- decodeBP_SW_circular(pos): the frontier of a new window = the degree-1 CNs of the position(s) that entered it
         if (tid == 0) { scal[S_PUSH + genq % 3] = 0; scal[S_OVF + genq % 3] = 0; }
         __syncthreads();
         {
             uint32_t *qc = (genq & 1) ? q1 : q0;
-            for (long long qq = (pos == 0 ? 0 : pos + W - 1); qq < pos + W; qq++) {
-                const int cs = (int)(qq % L) * C;
-                for (int k = tid; k < C; k += kThreads) {
-                    const uint32_t w = ldcn(cs + k);
-                    if ((w >> kCntShift) == 1u) {                                 // the queues hold the VN to release
-                        const int idx = atomicAdd(&scal[S_PUSH + genq % 3], 1);
-                        if (idx < kQCap) qc[idx] = w & kSumMask; else scal[S_OVF + genq % 3] = 1;
+            for (int d = (pos == 0 ? 0 : W - 1); d < W; d++) {
+                const int cs = cslot(d);
+                for (int w0 = (tid >> 6) * 64; w0 < Cw; w0 += kThreads) {
+                    const int w = w0 + lane;
+                    uint32_t z = 0;
+                    if (w < Cw) {
+                        const uint32_t y = cnt[cs + w] ^ 0x11111111u;    // nibble == 1  <=>  zero nibble of y
+                        z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+                        if (w * 8 + 8 > C) z &= (1u << (4 * (C - w * 8))) - 1u;
+                    }
+                    const int minen = __popc(z);
+                    const int incl = (int)wave_inclusive_scan((uint32_t)minen);
+                    const int tot = __builtin_amdgcn_readlane(incl, 63);
+                    if (tot == 0) continue;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&scal[S_PUSH + genq % 3], tot);
+                    int idx = __builtin_amdgcn_readfirstlane(base) + incl - minen;
+                    while (z) {
+                        const int k = (__ffs((int)z) - 1) >> 2;
+                        z &= z - 1;
+                        if (idx < kQCap) qc[idx] = ((uint32_t)(d + 2 * DV) << 16) | (uint32_t)(w * 8 + k); else scal[S_OVF + genq % 3] = 1;
+                        idx++;
                     }
                 }
             }
@@ -340,53 +490,91 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         STAMP(1);
         int ncur = min(scal[S_PUSH + genq % 3], kQCap);
         bool rescan = scal[S_OVF + genq % 3] != 0;
-        const int basemod = (int)(((pos - ms) % L + L) % L);
         for (;;) {
             uint32_t *qc = (genq & 1) ? q1 : q0, *qn = (genq & 1) ? q0 : q1;
             int *push_cnt = &scal[S_PUSH + (genq + 1) % 3], *push_ovf = &scal[S_OVF + (genq + 1) % 3];
             if (tid == 0) { scal[S_PUSH + (genq + 2) % 3] = 0; scal[S_OVF + (genq + 2) % 3] = 0; }
-            // Release VN j, the lone erased neighbour of some window CN.  A level costs two dependent trips to the L2
-            // instead of four: the queue names the VN (a CN whose count drops 2 -> 1 is left with Σ ids − j: no read of the
-            // CN word next round), and the VN's row is fetched beside the claim of its S bit, not after it.  The claim is
-            // the guard: an entry whose VN was released meanwhile (by another CN, or named twice) finds the bit clear.
-            // (Letting a thread follow its chain past the barrier was tried: one thread then walks what a round spreads
-            // over the workgroup — 1.75 times the time.)
-            auto release = [&](int j) {
-                const int slot_j = j / V, t = j - slot_j * V;
-                const uint32_t bit = 1u << (t & 31);
-                uint16_t loc[8];
-                if (dv == 4) {
-                    const uint2 r = *reinterpret_cast<const uint2 *>(adj + (size_t)j * 4);
-                    loc[0] = (uint16_t)r.x; loc[1] = (uint16_t)(r.x >> 16); loc[2] = (uint16_t)r.y; loc[3] = (uint16_t)(r.y >> 16);
-                } else {
-                    for (int i = 0; i < dv; i++) loc[i] = adj[(size_t)j * dv + i];
+            // CN l of position pos + d is believed to hold one erased neighbour: release it unless it is frozen.  Two trips
+            // to memory: the CN's sockets, then the VN's row (issued before the claim of its S bit); every atomic is in LDS.
+            // out[i] = 1 + [CN position offset + 2dv | CN] of edge i if this release left that CN with one erased neighbour
+            // inside the CN window.
+            auto release = [&](int d, int l, uint32_t (&out)[4]) {
+                const uint16_t *row = cnsock + ((size_t)lslot(d) * C + l) * dc;
+                uint32_t sk[8];
+                if (dc == 8) {
+                    const uint4 s4 = *reinterpret_cast<const uint4 *>(row);
+                    sk[0] = s4.x & 0xFFFFu; sk[1] = s4.x >> 16; sk[2] = s4.y & 0xFFFFu; sk[3] = s4.y >> 16;
+                    sk[4] = s4.z & 0xFFFFu; sk[5] = s4.z >> 16; sk[6] = s4.w & 0xFFFFu; sk[7] = s4.w >> 16;
                 }
-                if (!(atomicAnd(&Sb[slot_j * wpp + (t >> 5)], ~bit) & bit)) return;
-                atomicSub(&pos_cnt[slot_j], 1);
-                const long long qj = pos - ms + ((slot_j - basemod + L) % L);     // absolute position of VN j
-                for (int i = 0; i < dv; i++) {
-                    const long long qc2 = qj + i;
-                    const int c2 = (int)(qc2 % L) * C + loc[i];
-                    const uint32_t old = atomicSub(&cn[c2], kCntOne + (uint32_t)j);
-                    if ((old >> kCntShift) == 2u && qc2 >= pos && qc2 < pos + W) { // a window CN is left with one VN
-                        const int idx = atomicAdd(push_cnt, 1);
-                        if (idx < kQCap) qn[idx] = (old & kSumMask) - (uint32_t)j; else *push_ovf = 1;
+                int jd = 1 << 20, jt = 0;                                // offset of the neighbour's position from pos
+                for (int k0 = 0; k0 < dc; k0 += 8) {
+                    if (dc != 8) for (int k = 0; k < 8; k++) sk[k] = k0 + k < dc ? row[k0 + k] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (sk[k] == 0xFFFFFFFFu) continue;
+                        const int i = (int)(sk[k] % DV), t = (int)(sk[k] / DV), dq = d - i;
+                        if (pos + dq < 0) continue;                      // the stream has no VN position before 0
+                        if ((Sr[sslot(dq) + (t >> 5)] >> (t & 31)) & 1u) { jd = dq; jt = t; }
                     }
                 }
+                if (jd == (1 << 20) || jd < -ms) return;                 // none left (released this round) or frozen (BPF:1285-1310)
+                const uint2 r = reinterpret_cast<const uint2 *>(adj)[(size_t)lslot(jd) * V + jt];
+                const uint32_t bit = 1u << (jt & 31);
+                if (!(atomicAnd(&Sr[sslot(jd) + (jt >> 5)], ~bit) & bit)) return;
+                atomicSub(&pos_cnt[lslot(jd)], 1);
+                const uint32_t ll[4] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16};
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < DV; i++)                             // the dv returning atomics go out back to back
+                    o[i] = atomicSub(&cnt[cslot(jd + i) + (ll[i] >> 3)], 1u << ((ll[i] & 7) * 4));
+#pragma unroll
+                for (int i = 0; i < DV; i++)
+                    if (((o[i] >> ((ll[i] & 7) * 4)) & 15u) == 2u && jd + i >= 0 && jd + i < W)    // 2 -> 1 inside the CN window
+                        out[i] = 1u + (((uint32_t)(jd + i + 2 * DV) << 16) | ll[i]);
+            };
+            // a wave appends its lanes' entries behind *push_cnt: one prefix scan + one LDS atomic per wave
+            auto append = [&](const uint32_t (&out)[4]) {
+                const int mine = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
+                const int incl = (int)wave_inclusive_scan((uint32_t)mine);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (tot == 0) return;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(push_cnt, tot);
+                int idx = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (out[i]) { if (idx < kQCap) qn[idx] = out[i] - 1u; else *push_ovf = 1; idx++; }
             };
             if (rescan) {
-                // queue overflow: walk every CN of the window (each CN is the lone holder of at most one VN, and a
-                // VN released here may promote further CNs into THIS round — allowed: the window runs to its
-                // fixpoint and only the fixpoint is observable)
-                for (long long qq = pos; qq < pos + W; qq++) {
-                    const int cs = (int)(qq % L) * C;
-                    for (int k = tid; k < C; k += kThreads) {
-                        const uint32_t w = ldcn(cs + k);
-                        if ((w >> kCntShift) == 1u) release((int)(w & kSumMask));
+                // queue overflow: walk every CN of the window (a VN released here may promote further CNs into THIS round —
+                // allowed: the window runs to its fixpoint and only the fixpoint is observable)
+                for (int d = 0; d < W; d++) {
+                    const int cs = cslot(d);
+                    for (int w0 = (tid >> 6) * 64; w0 < Cw; w0 += kThreads) {        // wave-uniform trip count (append scans)
+                        const int w = w0 + lane;
+                        uint32_t z = 0;
+                        if (w < Cw) {
+                            const uint32_t y = cnt[cs + w] ^ 0x11111111u;
+                            z = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+                            if (w * 8 + 8 > C) z &= (1u << (4 * (C - w * 8))) - 1u;
+                        }
+                        while (__any(z != 0u)) {
+                            uint32_t out[4] = {0, 0, 0, 0};
+                            if (z) {
+                                const int k = (__ffs((int)z) - 1) >> 2;
+                                z &= z - 1;
+                                release(d, w * 8 + k, out);
+                            }
+                            append(out);
+                        }
                     }
                 }
             } else {
-                for (int k = tid; k < ncur; k += kThreads) release((int)qc[k]);
+                for (int k0 = (tid >> 6) * 64; k0 < ncur; k0 += kThreads) {
+                    uint32_t out[4] = {0, 0, 0, 0};
+                    if (k0 + lane < ncur) release((int)(qc[k0 + lane] >> 16) - 2 * DV, (int)(qc[k0 + lane] & 0xFFFFu), out);
+                    append(out);
+                }
             }
             __syncthreads();
             rescan = *push_ovf != 0;
@@ -395,34 +583,40 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
             if (ncur == 0 && !rescan) break;                                      // nothing left to fire (BPF:1454-1455)
         }
         STAMP(2);
-        // decision on position pos-ms (BPF:1445-1449), VNerased := S there
-        int nep = 0;
-        if (pd >= 0) {
-            const int slot = (int)(pd % L);
-            nep = pos_cnt[slot];
-            for (int w = tid; w < wpp; w += kThreads) Eb[slot * wpp + w] = Sb[slot * wpp + w];
-        }
+        // decision on position pos - ms (BPF:1445-1449): its S bits are VNerased from now on (frozen)
+        const int nep = pd >= 0 ? pos_cnt[lslot(-ms)] : 0;
         if (tid == 0) { acc[C_NE] += nep; if (nep > 0) acc[C_BE] += 1; }           // BPF:1480-1483
-        __syncthreads();
-        // size-2 stopping-set expurgation of position pos-2dv+1 (get_deg_two_ss, BPF:1227-1283, 1485-1497)
+        // size-2 stopping-set expurgation of position pos - 2dv + 1 (get_deg_two_ss, BPF:1227-1283, 1485-1497): an erased VN
+        // whose dv CNs all hold exactly two erased neighbours, the other one the same VN of the same position each time
         if (pe >= 0) {
-            const int slot = (int)(pe % L);
+            const int de = -(2 * DV - 1), sb = sslot(de), ls = lslot(de);
             int mine = 0;
-            for (int w = tid; w < wpp; w += kThreads) {
-                uint32_t x = Eb[slot * wpp + w];
-                while (x) {
-                    const int b = __ffs((int)x) - 1;
-                    x &= x - 1;
-                    const int t = w * 32 + b, va = slot * V + t;
-                    bool pair = true;
-                    int partner = -1;
-                    for (int i = 0; i < dv; i++) {
-                        const uint32_t s = ldcn((int)((pe + i) % L) * C + adj[(size_t)va * dv + i]);
-                        const int b2 = (int)((s & kSumMask) - (uint32_t)va);
-                        if ((s >> kCntShift) != 2u || (i > 0 && b2 != partner)) { pair = false; break; }
-                        partner = b2;
+            if (pos_cnt[ls] > 0) {
+                for (int w = tid; w < wpp; w += kThreads) {
+                    uint32_t x = Sr[sb + w];
+                    while (x) {
+                        const int b = __ffs((int)x) - 1;
+                        x &= x - 1;
+                        const int t = w * 32 + b;
+                        const uint2 r = reinterpret_cast<const uint2 *>(adj)[(size_t)ls * V + t];
+                        const uint32_t l[4] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16};
+                        bool pair = true;
+#pragma unroll
+                        for (int i = 0; i < DV; i++) pair = pair && ((cnt[cslot(de + i) + (l[i] >> 3)] >> ((l[i] & 7) * 4)) & 15u) == 2u;
+                        int partner = -1;
+                        for (int i = 0; i < DV && pair; i++) {            // the other erased neighbour, if it is in position pe
+                            const uint16_t *row = cnsock + ((size_t)lslot(de + i) * C + l[i]) * dc;
+                            int other = -1;
+                            for (int k = 0; k < dc; k++) {
+                                const uint32_t s = row[k];
+                                const int i2 = (int)(s % DV), t2 = (int)(s / DV);
+                                if (i2 == i && t2 != t && ((Sr[sb + (t2 >> 5)] >> (t2 & 31)) & 1u)) other = t2;
+                            }
+                            if (other < 0 || (i > 0 && other != partner)) pair = false;
+                            partner = other;
+                        }
+                        mine += pair ? 0 : 1;
                     }
-                    mine += 1 - (pair && partner / V == slot ? 1 : 0);
                 }
             }
             const uint32_t tot = wave_inclusive_scan((uint32_t)mine);
@@ -441,52 +635,59 @@ __device__ __forceinline__ void stream_bp_body(const Args &a)
         }
         __syncthreads();
         STAMP(3);
-        if constexpr (GEN) { generate(gen); gen++; }                              // BPF:2036-2045 (one-kernel form)
-        STAMP(6);
+        cb = cb + 1 == R ? 0 : cb + 1;                      // the decoder moves on: every relative offset shifts by one
+        vb = vb + 1 == RV ? 0 : vb + 1;
+        lb = lb + 1 == L ? 0 : lb + 1;
     }
     STAMP_FLUSH();
 
+    // ---- the window's state goes back to the blob until the next launch ---------------------------------------------------
     __syncthreads();
+    for (int i = tid; i < R * Cw; i += kThreads) ring_cnt[i] = cnt[i];
+    for (int i = tid; i < RV * wpp; i += kThreads) ring_s[i] = Sr[i];
     for (int i = tid; i < L; i += kThreads) pos_cnt_g[i] = pos_cnt[i];
     if (tid == 0) {
         for (int k = C_NE; k <= C_GBLE; k++) cnt64[k] = acc[k];
-        cnt64[C_POS] = pos; cnt64[C_GEN] = gen;
+        cnt64[C_POS] = pos;
         if (a.counters_out) {
             long long *o = a.counters_out + (size_t)blockIdx.x * 10;
             for (int k = C_NE; k <= C_GBLE; k++) o[k] = acc[k];
-            o[8] = pos; o[9] = gen;
+            o[8] = pos;
         }
     }
 }
 
-template <int ROWS>
-__global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_gen_kernel(const Args a)
+template <int DV>
+__global__ __launch_bounds__(kDecThreads, 4) __attribute__((amdgpu_num_sgpr(96))) void stream_dec_kernel(const Args a)
 {
-    stream_bp_body<ROWS, true, false, kGenThreads>(a);
+    stream_dec_body<DV>(a);
 }
 
-__global__ __launch_bounds__(kDecThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void stream_dec_kernel(const Args a)
-{
-    stream_bp_body<1, false, true, kDecThreads>(a);
-}
-
-
-int make_state_layout(const scldpc_code_params *p, StateLayout *lay)
+int make_state_layout(const scldpc_code_params *p, int W, StateLayout *lay)
 {
     const size_t L = p->L, V = p->vns_pos, C = p->cns_pos, S = (size_t)p->cns_pos * p->dc, dv = p->dv;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     lay->wpp = (int)((V + 31) / 32);
+    lay->Cw = (int)((C + 7) / 8);
+    lay->R = W + 3 * p->dv - 2;                     // CN positions pos - 2dv + 1 .. pos + W + dv - 2
+    lay->RV = W + 2 * p->dv - 1;                    // VN positions pos - 2dv + 1 .. pos + W - 1
     lay->adj = take(L * V * dv * 2);
+    lay->cnsock = take(L * S * 2);
     lay->inter = take(dv * S * 2);
     lay->sbits = take(L * lay->wpp * 4);
-    lay->ebits = take(L * lay->wpp * 4);
-    lay->cn = take(L * C * 4);
+    lay->ring_cnt = take((size_t)lay->R * lay->Cw * 4);
+    lay->ring_s = take((size_t)lay->RV * lay->wpp * 4);
     lay->poscnt = take(L * 4);
     lay->gkey = take(S * 8); lay->wlist = take(S * 8);
     lay->counters = take(C_NCOUNT * 8);
     lay->total = off;
     return 0;
+}
+
+size_t dec_lds_bytes(const StateLayout &lay)
+{
+    return 4u * ((size_t)16 + (size_t)lay.R * lay.Cw + (size_t)lay.RV * lay.wpp + 2 * kQCap + kMaxL + S_NSCAL);
 }
 
 int check_stream(const scldpc_code_params *p, int W, const char *who)
@@ -497,9 +698,13 @@ int check_stream(const scldpc_code_params *p, int W, const char *who)
     // the stream is generated L/2 positions ahead (BPF:2001): the window and the CNs of its VNs must exist already
     if (W < 1 || W + p->dv - 1 > p->L / 2)
         return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "%s: need 1 <= W and W + dv - 1 <= L/2 (W=%d, L=%d)", who, W, p->L);
-    if ((int64_t)p->cns_pos * p->dc > 65536 || p->dc > 15 || p->dv > 8 ||
-        (int64_t)p->dc * p->L * p->vns_pos >= (1ll << kDegShift))
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: ensemble too large for the streaming kernel", who);
+    if (p->dv != 4 || (int64_t)p->cns_pos * p->dc > 65536 || p->dc > 15)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the streaming kernels take dv = 4, dc <= 15 and at most 65536 "
+                                 "sockets per position", who);
+    StateLayout lay;
+    make_state_layout(p, W, &lay);
+    if (dec_lds_bytes(lay) > (size_t)scldpc::kMaxLdsBytes)
+        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: the window's state (%zu bytes) does not fit the LDS", who, dec_lds_bytes(lay));
     return SCLDPC_OK;
 }
 
@@ -509,7 +714,7 @@ extern "C" int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_
 {
     if (int rc = check_stream(p, W, "scldpc_stream_state_bytes")) return rc;
     StateLayout lay;
-    make_state_layout(p, &lay);
+    make_state_layout(p, W, &lay);
     return (int64_t)lay.total;
 }
 
@@ -547,20 +752,22 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
         if (c < x) c += 1.0;
         a.thresh = (uint32_t)c;
     }
-    make_state_layout(p, &a.lay);
+    make_state_layout(p, W, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
     a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos; a.ext_pos0 = ext_pos0;
     const int rows = a.nb / kGenThreads;
-    const size_t lds_dec = 4u * ((size_t)2 * kQCap + 32 + kMaxL + S_NSCAL + 2 * 8);
-    const size_t lds_gen = lds_dec + 4u * ((size_t)a.nb / 2) + (((size_t)a.S + 15) & ~(size_t)15);
+    const size_t lds_dec = dec_lds_bytes(a.lay);
+    const size_t lds_gen = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb / 2) + (((size_t)a.S + 15) & ~(size_t)15);
     if (lds_gen > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_gen);
     void (*gen_kern)(const Args) = rows == 1 ? stream_gen_kernel<1> : rows == 2 ? stream_gen_kernel<2>
                                    : rows == 4 ? stream_gen_kernel<4> : rows == 8 ? stream_gen_kernel<8> : stream_gen_kernel<16>;
+    void (*dec_kern)(const Args) = stream_dec_kernel<4>;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(gen_kern))) return rc_;
+    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(dec_kern))) return rc_;
     // Cycles of GENERATE (run `ahead` positions beyond the reference's lag of L/2) and DECODE (as many positions as are
     // then generated far enough: decodeBP_SW_circular(pos) needs positions up to pos + W + dv - 2).  `ahead` is bounded by the
-    // ring: generating position g re-uses the slots of VN position g - L and CN position g + dv - 1 - L, and the decoder
+    // buffer: generating position g re-uses the slots of VN position g - L and CN position g + dv - 1 - L, and the decoder
     // still reads CN position pos - 2dv + 1 (expurgation): ahead <= ceil(L/2) - 3dv + 2.  The call ends as main_streaming
     // leaves a stream: generated = decoded + L/2.
     const int half = p->L / 2, ahead_max = std::max(0, (p->L - half) - 3 * p->dv + 2);
@@ -572,7 +779,7 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
         a.gen_ahead = ahead; a.npos = 0;
         hipLaunchKernelGGL(gen_kern, dim3(nstreams), dim3(kGenThreads), lds_gen, hs, a);
         a.npos = c; a.trace_off = done;
-        hipLaunchKernelGGL(stream_dec_kernel, dim3(nstreams), dim3(kDecThreads), lds_dec, hs, a);
+        hipLaunchKernelGGL(dec_kern, dim3(nstreams), dim3(kDecThreads), lds_dec, hs, a);
         done += c;
     }
     a.gen_ahead = 0; a.npos = 0;                                    // a new stream's first L/2 positions, or catching up

@@ -50,7 +50,7 @@ out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
 if "--stream" in sys.argv:                      # BASELINE config 5: where does a decoded position's time go?
     ps = E.make_params(4, 8, 50, 5000)
-    NS = 512
+    NS = 2048
     buf = torch.zeros((NS, 16), dtype=torch.int64, device="cuda")
     assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
     st = E.Streams(ps, NS, seed=1, eps=0.485, W=20, doped=(10, 11, 12))
@@ -58,7 +58,7 @@ if "--stream" in sys.argv:                      # BASELINE config 5: where does 
     torch.cuda.synchronize()
     buf.zero_()
     st.run(16)
-    show("stream_bp_kernel (16 positions)", ["(loop top)", "window frontier", "window rounds", "decision + expurgation",
+    show("stream_gen_kernel + stream_dec_kernel (16 positions; sums over both kernels of a stream)", ["(loop top)", "window frontier", "window rounds", "decision + expurgation",
                                              "generate: ranking (straddlers + rest)", "generate: channel", "generate: wiring",
                                              "ranking: draw + count", "ranking: scan", "ranking: classify"])
 it = out["counters"][:, 5].float().mean().item()
