@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--flooding", action="store_true",
                     help="C2: decode one flooding iteration per barrier round (scldpc_full_bp_device_cn16; with --gen1 the "
                          "16-bit-CN-word kernel): reports the iteration count and the literal-flooding figure")
+    ap.add_argument("--traj", action="store_true",
+                    help="C2: the trajectory build's decoder (bp_traj): one flooding iteration per round AND the per-iteration rows "
+                         "(deg_1_iter, recovered, first erased position) written for every trial")
     ap.add_argument("--overlap", action="store_true",
                     help="(default) two streams, two buffers: the sampler of step k+1 fills the tail of the decoder of step k")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: sample, then decode, then accumulate")
@@ -265,6 +268,10 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     EPS = 0.48 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch or 32768
+    TRAJ_ROWS = 640                                     # iterations kept per trial in --traj mode (the longest run at this size: ~520)
+    if a.traj:
+        a.flooding = True                               # the rows come from the iteration-exact decoder
+        B = a.batch or 16384                            # 16384 x 640 x 12 B of rows per step
     workload = f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} full BP unlimited iterations"
     gen2 = not (a.gen1 or a.adj32)
     if gen2 and not E.cn16_supported(p):
@@ -303,7 +310,9 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
             s_dec.wait_event(sampled[b])
             if e:
                 e[2].record(s_dec)
-            if a.flooding and gen2:
+            if a.traj and gen2:
+                E.full_bp_cn16(p, d_adj[b], d_cn[b], d_ch[b], counters=d_cnt[b], rows_cap=TRAJ_ROWS)
+            elif a.flooding and gen2:
                 E.full_bp_cn16(p, d_adj[b], d_cn[b], d_ch[b], counters=d_cnt[b])
             elif a.flooding:
                 E.full_bp(p, d_adj[b], d_ch[b], counters=d_cnt[b])
@@ -382,7 +391,8 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": workload, "trials_per_gpu_per_step": B,
                    "step": "device sample (code+channel) -> decodeBP -> plr_computation",
-                   "decoder": ("flooding, one barrier round per iteration (iteration counts and caps as the reference's)" if a.flooding else
+                   "decoder": ("bp_traj: flooding, one barrier round per iteration, per-iteration rows written (BPT:988,1051)" if a.traj else
+                               "flooding, one barrier round per iteration (iteration counts and caps as the reference's)" if a.flooding else
                                "fixpoint of unlimited flooding by chain-following peeling (every output of decodeBP "
                                "except the iteration count; equality with the flooding kernel on every trial is a test)"),
                    "kernels": "sampler_v2 + full_bp_small (4-bit CN counts, CN->VN table)" if gen2 else "first generation",

@@ -37,6 +37,7 @@
 #include "kernel_util.h"
 #include "philox.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -48,7 +49,7 @@ enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
-    size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, poscnt, gkey, wlist, counters, total;
+    size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, poscnt, gkey, wlist, tslg, counters, total;
     int wpp;                // 32-bit words of S bits per position
     int Cw;                 // 32-bit words of count nibbles per CN position
     int R, RV;              // ring slots: CN positions / VN positions the decoder keeps in LDS
@@ -57,6 +58,7 @@ struct StateLayout {        // byte offsets inside one stream's blob
 struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
     int gen_ahead;              // GENERATE: until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
+    int force_wide;             // diagnostics / tests: rank every position by the 16-bit-counter fallback
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
@@ -96,8 +98,8 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     extern __shared__ uint32_t lds[];
     uint32_t *wsum = lds;                                               // scan scratch
     int *scal = reinterpret_cast<int *>(wsum + 32);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // nb 16-bit bucket counters, two per word (ranking); then the CN-row stage
-    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb / 2);         // [S] arrival slot of every socket's key in its bucket; then the CN fill counters
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // nb words of four nibble-wide bucket counters (ranking); then the CN-row stage
+    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb);             // [S/2] arrival slots (nibbles) of the sockets' keys; then the CN fill counters
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, wpp = a.lay.wpp;
@@ -119,14 +121,10 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     long long gen = cnt64[C_GEN];
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
-    auto rank_position = [&](long long cpos) {
-        if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
-            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
-            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
-            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
-            __syncthreads();
-            return;
-        }
+    // Ranking with 16-bit bucket counters (a.nb buckets, two per word, arrival slots as bytes in the blob): the fallback of
+    // rank_nib below for a position in which sixteen keys meet in one of its fine buckets — never on real draws.
+    auto rank_wide = [&](long long cpos) {
+        uint8_t *tsl = reinterpret_cast<uint8_t *>(st + a.lay.tslg);
         // Keys are never stored: Philox is pure VALU, so the three passes (count, classify, rank the straddlers) draw them
         // again; what a pass hands to the next lives in LDS (16-bit prefix per bucket, one byte of arrival slot per socket)
         // except the straddling buckets' keys, which are grouped in the stream's blob (3-15 % of the sockets).
@@ -251,6 +249,127 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     };
 
 
+    // Round 3: four nibble-wide counters per word plus the word's 16-bit first rank (sampler_v2.hip's histogram) — four
+    // times as many buckets in twice the LDS, so a quarter of the keys sit in buckets that straddle two CNs (3.8 % at
+    // N = 5000 instead of 15 %) and a quarter of the straddlers' records travel through the blob.  The arrival slots are
+    // nibbles too (one 16-bit store per Philox call).  Returns false (for every thread) when a bucket met a sixteenth key.
+    auto rank_nib = [&](long long cpos) -> bool {
+        const int ncalls = (S + 3) / 4, nbw = a.nb, bshift = a.shift - 2;
+        uint16_t *tsl16 = reinterpret_cast<uint16_t *>(tsl);
+        uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));          // (no Philox round keys hoisted out of the position loop and spilled)
+        for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
+        if (tid == 0) { scal[S_WL] = 0; scal[S_OVF] = 0; }
+        __syncthreads();
+        uint32_t crowded = 0;
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4], pk = 0;
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (q * 4 + u < S) {
+                    const uint32_t b = r[u] >> bshift, sh = (b & 3u) * 4u;
+                    const uint32_t sl = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 15u;
+                    pk |= sl << (4 * u);
+                    crowded |= sl + 1u;
+                }
+            }
+            tsl16[q] = (uint16_t)pk;
+        }
+        if (crowded & 16u) scal[S_OVF] = 1;                 // a nibble wrapped
+        __syncthreads();
+        STAMP(7);
+        if (scal[S_OVF] || a.force_wide) { __syncthreads(); return false; }
+        // exclusive scan of the bucket counts: thread t owns words t*ROWS .. t*ROWS+ROWS-1; the word's first rank goes into
+        // its high half
+        {
+            uint32_t x[ROWS], v[ROWS], tot = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                x[r] = hist[tid * ROWS + r];
+                const uint32_t sb = (x[r] & 0x0F0Fu) + ((x[r] >> 4) & 0x0F0Fu);
+                v[r] = (sb + (sb >> 8)) & 0xFFu;
+                tot += v[r];
+            }
+            const uint32_t inc = wave_inclusive_scan(tot);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            const uint32_t wt = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t winc = wave_inclusive_scan(wt);
+            uint32_t pre = inc - tot + (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { hist[tid * ROWS + r] = x[r] | (pre << 16); pre += v[r]; }
+        }
+        __syncthreads();
+        STAMP(8);
+        auto cn_of = [&](uint32_t rank) { return (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc); };
+        auto straddles = [&](uint32_t g0, uint32_t cnt) {
+            return cnt > 1u && (a.dc_shift >= 0 ? (g0 >> a.dc_shift) != ((g0 + cnt - 1u) >> a.dc_shift)
+                                                : g0 / (uint32_t)a.dc != (g0 + cnt - 1u) / (uint32_t)a.dc);
+        };
+        // first rank and size of a key's bucket from its word
+        auto bucket_of = [&](uint32_t k, uint32_t &g0, uint32_t &cnt) {
+            const uint32_t b = k >> bshift, sh = (b & 3u) * 4u, x = hist[b >> 2], below = x & ((1u << sh) - 1u);
+            g0 = ((x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu)) & 0xFFFFu;
+            cnt = (x >> sh) & 0xFu;
+        };
+        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
+            const uint32_t slots = tsl16[q];
+            uint32_t c4[4] = {0, 0, 0, 0};                  // (a straddler's entry is written by the third pass)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s >= S) continue;
+                uint32_t g0, cnt;
+                bucket_of(r[u], g0, cnt);
+                if (!straddles(g0, cnt)) { c4[u] = cn_of(g0); continue; }
+                gkey[g0 + ((slots >> (4 * u)) & 15u)] = make_uint2(r[u], (uint32_t)s);
+                wlist[atomicAdd(&scal[S_WL], 1)] = make_uint2(r[u], (uint32_t)s | (g0 << 16));
+            }
+            if (q * 4 + 3 < S && (S & 3) == 0) {
+                *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
+            } else {
+                for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
+            }
+        }
+        __syncthreads();
+        STAMP(9);
+        {
+            const int nwl = scal[S_WL];
+            for (int w = tid; w < nwl; w += kThreads) {
+                const uint2 e = wlist[w];
+                const uint32_t k = e.x, s = e.y & 0xFFFFu;
+                uint32_t g0, cnt;
+                bucket_of(k, g0, cnt);
+                uint32_t rank = g0;                         // the mates' records, four at a time; a key's own compares false
+                for (uint32_t g = g0; g < g0 + cnt; g += 4) {
+                    uint2 m[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) m[i] = g + i < g0 + cnt ? gkey[g + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
+                }
+                dst[s] = cn_of(rank);
+            }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    auto rank_position = [&](long long cpos) {
+        if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
+            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
+            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
+            __syncthreads();
+            return;
+        }
+        if (!rank_nib(cpos)) rank_wide(cpos);
+    };
+
     // ---- the CN -> socket rows of CN position cpos from its finished socket -> CN row: the ranking's LDS is free now, so
     //      the rows are staged there (a nibble-wide fill counter per CN hands out the dc places of a row: which place a
     //      socket gets is immaterial, consumers treat a row as a set) and written out whole, `chunk` CNs at a time -------
@@ -258,7 +377,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         const uint16_t *row = inter + (size_t)(cpos % dv) * S;
         uint16_t *stage = reinterpret_cast<uint16_t *>(hist);
         uint32_t *fill = reinterpret_cast<uint32_t *>(tsl);
-        const int chunk = std::min(C, (a.nb / a.dc) & ~7);                // CNs per pass: the stage holds a.nb sockets (2 bytes each)
+        const int chunk = std::min(C, (2 * a.nb / a.dc) & ~7);            // CNs per pass: the stage holds 2 * a.nb sockets (2 bytes each)
         uint16_t *dst = cnsock + (size_t)(cpos % L) * C * a.dc;
         for (int c0 = 0; c0 < C; c0 += chunk) {
             const int c1 = std::min(C, c0 + chunk);
@@ -680,6 +799,7 @@ int make_state_layout(const scldpc_code_params *p, int W, StateLayout *lay)
     lay->ring_s = take((size_t)lay->RV * lay->wpp * 4);
     lay->poscnt = take(L * 4);
     lay->gkey = take(S * 8); lay->wlist = take(S * 8);
+    lay->tslg = take(S);                            // arrival slots of the 16-bit-counter fallback ranking
     lay->counters = take(C_NCOUNT * 8);
     lay->total = off;
     return 0;
@@ -757,7 +877,8 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos; a.ext_pos0 = ext_pos0;
     const int rows = a.nb / kGenThreads;
     const size_t lds_dec = dec_lds_bytes(a.lay);
-    const size_t lds_gen = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb / 2) + (((size_t)a.S + 15) & ~(size_t)15);
+    const size_t lds_gen = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb) + (((size_t)a.S / 2 + 8 + 15) & ~(size_t)15);
+    if (const char *v = getenv("SCLDPC_DEBUG_STREAM_WIDE")) a.force_wide = atoi(v);         // diagnostics / tests only
     if (lds_gen > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_gen);
     void (*gen_kern)(const Args) = rows == 1 ? stream_gen_kernel<1> : rows == 2 ? stream_gen_kernel<2>

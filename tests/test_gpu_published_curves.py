@@ -182,9 +182,14 @@ def test_bp_trajectories_reproduce_the_published_files_statistics(E, tag, frames
     o1 = torch.zeros((3, cap), dtype=torch.float64, device="cuda")
     o2 = torch.zeros((3, cap), dtype=torch.float64, device="cuda")
     tt = torch.arange(cap, device="cuda")[None, :]
-    for b0 in range(0, frames, batch):
-        adj, ch = E.sample_philox(p, 4711, b0, batch, m["eps"], adj16=True)
-        out = E.full_bp(p, adj, ch, max_it=cap, is_term=bool(m["is_term"]), rows_cap=cap)
+    small = E.full_bp_sock16_supported(p)                  # L = 100, N = 1000 (n = 100 000): the 4-bits-per-CN level kernel on the
+    for b0 in range(0, frames, batch):                     # CN -> socket table writes the rows; N = 5000: the 16-bit-word kernel
+        if small:
+            adj, cs, ch = E.sample_philox_sock16(p, 4711, b0, batch, m["eps"])
+            out = E.full_bp_cn16(p, adj, cs, ch, max_it=cap, is_term=bool(m["is_term"]), rows_cap=cap, sockets=True)
+        else:
+            adj, ch = E.sample_philox(p, 4711, b0, batch, m["eps"], adj16=True)
+            out = E.full_bp(p, adj, ch, max_it=cap, is_term=bool(m["is_term"]), rows_cap=cap)
         its = out["counters"][:, 5]
         assert int(out["counters"][:, 6].min().item()) == 0 and int(its.max().item()) <= cap
         live = (tt < its[:, None]).double()                               # [batch, cap]

@@ -36,6 +36,25 @@ def test_streams_equal_cpu_twin(E, oracle, L, N, eps, W, doped, chunks):
             assert cnt[s, :8].tolist() == [o[f] for f in oracle.Stream.FIELDS[2:]] and cnt[s, 8] == o["pos"] + 1
 
 
+@pytest.mark.parametrize("L,N,eps,W,doped", [(30, 100, 0.49, 12, (10, 11, 12)), (50, 1000, 0.485, 20, (10, 11, 12)), (50, 5000, 0.47, 20, ())])
+def test_ranking_fallback_with_16_bit_counters_gives_the_same_stream(E, oracle, monkeypatch, L, N, eps, W, doped):
+    """The generation kernel ranks a CN position's keys with nibble-wide bucket counters; a position in which sixteen keys
+    meet in one bucket (never on real draws) is ranked again with 16-bit counters.  Forced here (SCLDPC_DEBUG_STREAM_WIDE):
+    the stream must still equal its CPU twin position by position."""
+    monkeypatch.setenv("SCLDPC_DEBUG_STREAM_WIDE", "1")
+    p = E.make_params(4, 8, L, N)
+    po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
+    st = E.Streams(p, 2, seed=23, eps=eps, W=W, doped=doped, stream0=9)
+    twins = [oracle.Stream(po, 23, eps, W, doped, rng_mode=1, decoder=1, sid=9 + s) for s in range(2)]
+    npos = 40 if N <= 1000 else 10
+    cnt, tr = st.run(npos, trace=True)
+    tr = tr.cpu().numpy()
+    for s in range(2):
+        for k in range(npos):
+            o = twins[s].step()
+            assert tr[s, k].tolist() == [o[f] for f in oracle.Stream.FIELDS], (L, N, s, k)
+
+
 def test_streaming_cli_writes_results_circular_rows(E, tmp_path):
     from fl_scaling_sc_ldpc_amd import bp_decoding as B
     B.streaming(["2", "6", "2", "5", "6", "--L", "20", "--N", "10", "--eps-ini", "0.47", "--num-points", "1",
