@@ -59,7 +59,7 @@ struct SmArgs {
 // TRAJ (with LEVEL): the trajectory rows of the BPT build — per iteration deg_1_iter, the VNs recovered and the position of
 // the first erased VN (BPT:988, 1037-1038, 1051), incl. iteration 0's count of degree-1 CNs whose only VN is known (BPF:973).
 template <int BLOCK, bool LEVEL, bool PERSIST, bool SOCK, bool TRAJ = false>
-__global__ __launch_bounds__(BLOCK, 7) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
+__global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
 {
     constexpr int kWaves = BLOCK / 64;
     extern __shared__ uint32_t lds[];

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernel_util.h"
 #include "philox.h"
+#include <cstdlib>
 
 namespace {
 
@@ -26,6 +27,8 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kMaxDoped = 32;
 
 struct SArgs {
+    int force_wide;             // diagnostics / tests: rank every position of the big kernel by the 16-bit-counter fallback
+    int fine;                   // big kernel: nb counter words (4 * nb nibble buckets) instead of nb / 2
     int dv, dc, L, cns_pos, vns_pos, n, S, D, nb, shift, lgchunk, dc_shift, nw;
     int ens, wrapL, pbits;      // ensemble: 0 Olmos chain, 1 tail-biting (stream and CN position wrap at wrapL = L), 2 protograph
     int ndoped;
@@ -347,7 +350,9 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                                                 : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
     };
 
-    for (int p = 0; p < a.D; p++) {
+    // Ranking of CN position p with the 16-bit bucket counters: round 3's fallback for a position in which sixteen keys meet in
+    // one of the nibble-wide counters of rank_nib below (never on real draws).
+    auto rank_wide = [&](int p) {
         for (int b = tid; b < nb / 2; b += kThreads) hist[b] = 0;
         if (tid == 0) wsum[kWaves] = 0;
         __syncthreads();
@@ -436,6 +441,113 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
             }
         }
         __syncthreads();
+    };
+
+    // Round 3 (as stream_bp.hip's generation): four nibble-wide counters per word plus the word's 16-bit first rank — twice as
+    // many buckets in the same LDS (nb / 2 words: 32768 buckets at N = 10000), so half as many keys sit in buckets that
+    // straddle two CNs (15 % instead of 30 %) and half as many straddler records travel through the workspace; the arrival
+    // slots are nibbles (one 16-bit store per Philox call).  Returns false (for every thread) when a bucket met a sixteenth key.
+    auto rank_nib = [&](int p) -> bool {
+        // a.fine: nb counter words (4 * nb buckets, twice the LDS: one workgroup per CU at N = 10000) instead of nb / 2
+        const int rn = a.fine ? ROWS : ROWS / 2;                            // counter words per thread
+        const int nbw = a.fine ? nb : nb / 2, bshift = a.fine ? a.shift - 2 : a.shift - 1;      // key >> bshift = fine bucket
+        uint16_t *tsl16 = reinterpret_cast<uint16_t *>(tsl);
+        uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));                          // (no Philox round keys hoisted and spilled)
+        for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
+        if (tid == 0) { wsum[kWaves] = 0; wsum[kWaves + 1] = 0; }
+        __syncthreads();
+        uint32_t crowded = 0;
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4], pk = 0;
+            philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, k_lo, k_hi, r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (q * 4 + u < S) {
+                    const uint32_t b = r[u] >> bshift, sh = (b & 3u) * 4u;
+                    const uint32_t sl = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 15u;
+                    pk |= sl << (4 * u);
+                    crowded |= sl + 1u;
+                }
+            }
+            tsl16[q] = (uint16_t)pk;
+        }
+        if (crowded & 16u) wsum[kWaves + 1] = 1u;                           // a nibble wrapped
+        __syncthreads();
+        if (wsum[kWaves + 1] || a.force_wide) { __syncthreads(); return false; }
+        {
+            uint32_t x[ROWS], v[ROWS], tot = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                x[r] = 0; v[r] = 0;
+                if (r < rn) {
+                    x[r] = hist[tid * rn + r];
+                    const uint32_t sb = (x[r] & 0x0F0Fu) + ((x[r] >> 4) & 0x0F0Fu);
+                    v[r] = (sb + (sb >> 8)) & 0xFFu;
+                    tot += v[r];
+                }
+            }
+            const uint32_t inc = wave_inclusive_scan(tot);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            const uint32_t wt = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t winc = wave_inclusive_scan(wt);
+            uint32_t pre = inc - tot + (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) if (r < rn) { hist[tid * rn + r] = x[r] | (pre << 16); pre += v[r]; }
+        }
+        __syncthreads();
+        auto bucket_of = [&](uint32_t k, uint32_t &g0, uint32_t &cnt) {     // first rank and size of a key's bucket
+            const uint32_t b = k >> bshift, sh = (b & 3u) * 4u, x = hist[b >> 2], below = x & ((1u << sh) - 1u);
+            g0 = ((x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu)) & 0xFFFFu;
+            cnt = (x >> sh) & 0xFu;
+        };
+        uint16_t *wp = win + (size_t)(p % dv) * S;
+        for (int q = tid; q < ncalls; q += kThreads) {
+            uint32_t r[4], c4[4] = {0, 0, 0, 0};                            // (a straddler's entry is written from the worklist)
+            philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, k_lo, k_hi, r);
+            const uint32_t slots = tsl16[q];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = q * 4 + u;
+                if (s >= S) continue;
+                uint32_t g0, cnt;
+                bucket_of(r[u], g0, cnt);
+                if (!straddles(g0, g0 + cnt)) { c4[u] = cn_of(g0); continue; }
+                gkey[g0 + ((slots >> (4 * u)) & 15u)] = make_uint2(r[u], (uint32_t)s);
+                wlist[atomicAdd(&wsum[kWaves], 1u)] = make_uint2(r[u], (uint32_t)s | (g0 << 16));
+            }
+            if (q * 4 + 3 < S && (S & 3) == 0) {
+                *reinterpret_cast<uint2 *>(wp + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
+            } else {
+                for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[q * 4 + u] = (uint16_t)c4[u];
+            }
+        }
+        __syncthreads();
+        {
+            const int nwl = (int)wsum[kWaves];
+            for (int w = tid; w < nwl; w += kThreads) {
+                const uint2 e = wlist[w];
+                const uint32_t k = e.x, s = e.y & 0xFFFFu;
+                uint32_t g0, cnt;
+                bucket_of(k, g0, cnt);
+                uint32_t rank = g0;
+                for (uint32_t g = g0; g < g0 + cnt; g += 4) {
+                    uint2 m[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) m[i] = g + i < g0 + cnt ? gkey[g + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
+                }
+                wp[s] = (uint16_t)cn_of(rank);
+            }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    for (int p = 0; p < a.D; p++) {
+        if (!rank_nib(p)) rank_wide(p);
         const int qpos = p - (dv - 1);
         if (qpos >= 0) {
             for (int t = tid; t < a.vns_pos; t += kThreads) {
@@ -535,13 +647,18 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         if (c < x) c += 1.0;
         a.thresh = (uint32_t)c;
     }
-    int off = big ? a.nb / 2 : (a.nb + 3) & ~3;
+    // nb counter words (4 * nb nibble buckets: 7.6 % of the keys in straddling buckets at N = 10000 instead of 15 %) at one
+    // workgroup per CU beat nb / 2 words at two: 105 against 165 ms per 8192 trials (profiles/r03_ab_c3_sampler.txt)
+    a.fine = 1;
+    if (const char *v = getenv("SCLDPC_SAMPLER_BIG_FINE")) a.fine = atoi(v) != 0;
+    int off = big ? (a.fine ? a.nb : a.nb / 2) : (a.nb + 3) & ~3;
     if (!big) {
         a.off_gkey = off; off += (a.S + 3) & ~3;
         a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
         a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
     }
     a.off_wsum = off; off += big ? 32 + (a.S + 15) / 16 * 4 : 32 + kWaves * kWaves;
+    if (const char *v = getenv("SCLDPC_DEBUG_SAMPLER_WIDE")) a.force_wide = atoi(v);          // diagnostics / tests only
     const size_t lds_bytes = 4u * (size_t)off;
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "%s: needs %zu B of LDS", who, lds_bytes);

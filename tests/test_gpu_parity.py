@@ -305,10 +305,14 @@ def test_ensembles_beyond_the_lds_use_the_global_workspace(E, oracle, L, N, eps)
                                       res["num_blocks_err_exp"], res["num_erasures_p1"]]
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("L,N,eps,doped", [(8, 5000, 0.47, ()), (6, 10000, 0.46, (2,)), (5, 16384, 0.5, ())])
-def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, L, N, eps, doped):
-    """More than 8192 sockets per position: the sampler's scratch moves to the workspace; same integers as the twin."""
+def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, monkeypatch, L, N, eps, doped, wide):
+    """More than 8192 sockets per position: the sampler's scratch moves to the workspace; same integers as the twin — through
+    the nibble-wide bucket counters (round 3) and through their 16-bit fallback (forced: SCLDPC_DEBUG_SAMPLER_WIDE)."""
     import torch
+    if wide:
+        monkeypatch.setenv("SCLDPC_DEBUG_SAMPLER_WIDE", "1")
     p = E.make_params(4, 8, L, N)
     po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
     T = 3
