@@ -423,24 +423,40 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
                                                         # rounds, the second fills the CUs the early finishers leave
     steps_pd = int(N_POS * L_CHAIN * (EPS + 0.1))       # PD:721 (non-terminated)
     total_size = p.cns_pos * L_CHAIN
-    d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev)
-    d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
+    # two (table, channel) buffers of 66 GB: the sampler of step k+1 runs on a second stream beside the picks of step k, whose
+    # launch ends in a tail of long trials on a mostly empty chip
+    nbuf = 1 if a.no_overlap else 2
+    d_adj = [torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+    d_ch = [torch.empty((B, p.nw), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     mom = torch.zeros((3, steps_pd + 1), dtype=torch.int64, device=dev)
-    ev = _events(a.steps, 3)
+    s_dec = torch.cuda.current_stream(dev)
+    s_samp = s_dec if nbuf == 1 else torch.cuda.Stream(dev)
+    sampled = [torch.cuda.Event() for _ in range(nbuf)]
+    decoded = [torch.cuda.Event() for _ in range(nbuf)]
+    ev = _events(a.steps, 4)
 
     def step(k, e=None):
         trial0 = (k * world + rank) * B
-        if e:
-            e[0].record()
-        E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj, d_ch))
-        if e:
-            e[1].record()
-        # the trajectories as rows (4 B per step and trial: 9.5 GB per batch) and one reduction pass: 7 % faster than three
-        # global atomics per step inside the chain of picks (tools/ab_c3.py)
-        r = E.peel_pick(p, d_adj, d_ch, total_size, steps_pd, seed=SEED, trial0=trial0, want_r1=True)
-        E.r1_moments(r["r1"], mom)
-        if e:
-            e[2].record()
+        b = k % nbuf
+        with torch.cuda.stream(s_samp):
+            s_samp.wait_event(decoded[b])
+            if e:
+                e[0].record(s_samp)
+            E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj[b], d_ch[b]))
+            if e:
+                e[1].record(s_samp)
+            sampled[b].record(s_samp)
+        with torch.cuda.stream(s_dec):
+            s_dec.wait_event(sampled[b])
+            if e:
+                e[2].record(s_dec)
+            # the trajectories as rows (4 B per step and trial: 9.5 GB per batch) and one reduction pass: 7 % faster than three
+            # global atomics per step inside the chain of picks (tools/ab_c3.py)
+            r = E.peel_pick(p, d_adj[b], d_ch[b], total_size, steps_pd, seed=SEED, trial0=trial0, want_r1=True)
+            E.r1_moments(r["r1"], mom)
+            if e:
+                e[3].record(s_dec)
+            decoded[b].record(s_dec)
 
     for k in range(a.warmup):
         step(k)
@@ -459,7 +475,7 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
     if rank != 0:
         return
     ms_s = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
-    ms_p = sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps
+    ms_p = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
     b_alg = 16 * p.n * p.dv + p.n // 8
     value = total / dt
     ach = b_alg * B / (ms_p * 1e-3) / 1e9
@@ -470,7 +486,8 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
            "config": {"workload": f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} random-pick peeling, "
                                   f"{steps_pd} steps per trial, non-terminated, moments of the degree-1 trajectories",
                       "trials_per_gpu_per_step": B, "step": "device sample -> peel_pick (r1 rows) -> r1_moments",
-                      "parallelism": f"trial-sharded x{world}"},
+                      "parallelism": f"trial-sharded x{world}",
+                      "streams": "sampler(k+1) || picks(k), double-buffered" if nbuf == 2 else "single stream"},
            "roofline": {"bound": "hbm", "kernel": "peel_pick_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("peel_pick_kernel", B, "C3")),
                         "alg_bytes_per_trial": b_alg, "moments_bytes_per_batch": 24 * (steps_pd + 1), "ms_per_launch": ms_p,
@@ -615,7 +632,7 @@ def run_c5(a, E, dev, rank, world, dist, fence, finish):
     # per decoded position one VN position (N rows of dv ids) and one CN position enter the buffer and are read by the window
     b_alg = 16 * N_POS * DV + N_POS // 8
     ach = b_alg * CHUNK * NS / (ms * 1e-3) / 1e9
-    tg, td = measured_traffic("stream_gen_kernel", NS, "C5"), measured_traffic("stream_dec_kernel", NS, "C5")
+    tg, td = measured_traffic("stream_gen_kernel", sizes[0], "C5"), measured_traffic("stream_dec_kernel", sizes[0], "C5")   # per launch of one half
     # (a step of 16 positions is one decode launch between two generate launches; the PMC figures are means per launch)
     tr = {"hbm_bytes": halves * (2 * tg["hbm_bytes"] + td["hbm_bytes"]),
           "hbm_bytes_raw": halves * (2 * tg["hbm_bytes_raw"] + td["hbm_bytes_raw"])} if tg and td else None

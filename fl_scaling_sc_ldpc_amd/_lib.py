@@ -43,7 +43,6 @@ EXPORTS = (
     "scldpc_stream_glibc_next_host", "scldpc_stream_run_device_inputs_at",
     "scldpc_full_bp_sock16_supported", "scldpc_full_bp_fixpoint_device_sock16", "scldpc_full_bp_device_sock16",
     "scldpc_full_bp_traj_device_cn16", "scldpc_full_bp_traj_device_sock16",
-    "scldpc_full_bp_vn16_supported", "scldpc_full_bp_fixpoint_device_vn16",
 )
 
 
@@ -120,8 +119,6 @@ def lib():
     L.scldpc_full_bp_device_sock16.argtypes = L.scldpc_full_bp_device_cn16.argtypes
     L.scldpc_full_bp_traj_device_cn16.argtypes = [pp, i32, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]
     L.scldpc_full_bp_traj_device_sock16.argtypes = L.scldpc_full_bp_traj_device_cn16.argtypes
-    L.scldpc_full_bp_vn16_supported.argtypes = [pp]
-    L.scldpc_full_bp_fixpoint_device_vn16.argtypes = [pp, i32, vp, vp, i32, vp, vp, vp]
     L.scldpc_full_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, u64, vp]
     L.scldpc_sw_bp_device.argtypes = [pp, i32, vp, vp, i32, i32, i32, vp, vp, vp, u64, vp]
     L.scldpc_sample_philox_device_adj16.argtypes = L.scldpc_sample_philox_device.argtypes

@@ -165,14 +165,12 @@ class Simulator:
         cn16 = small and (E.cn16_supported(p) or self.sock)
         self.gen2 = cn16 and self.rows_cap == 0 and self.schedule == "fixpoint" and (self.max_it <= 0 or self.max_it >= 1000000)
         self.lvl2 = cn16 and not self.gen2
-        # N <= 512: the fixpoint needs no CN -> VN table at all (count + socket sum per CN, full_bp_sum.hip)
-        self.sum2 = bool(self.gen2 and not self.sock and E.vn16_supported(p))
         # square-window decoding with the window's state in LDS reads a CN -> socket table: sampled with the code where the
         # second-generation sampler takes the ensemble (else E.sw_bp builds it in a pass of its own)
         self.ring2 = (self.rng == "philox" and self.decoder == "sw" and adj_dtype == torch.int16
                       and E.sock16_supported(p) and E.sw_ring_supported(p, self.W))
         self.d_cn = (torch.empty((batch, p.nk, p.dc), dtype=torch.int16, device=self.device)
-                     if ((self.gen2 and not self.sum2) or self.lvl2 or self.ring2) else None)
+                     if (self.gen2 or self.lvl2 or self.ring2) else None)
         if self.verbose:
             print("[scldpc] kernels: " + self.kernel_choice(), file=sys.stderr, flush=True)
 
@@ -185,8 +183,6 @@ class Simulator:
         samp = "glibc replay on the host" if self.rng == "glibc" else \
             ("sampler_v3 (CN->socket table)" if self.sock else "sampler_v3 (CN->VN table)") if (self.gen2 or self.lvl2) \
             else "sampler (first generation)"
-        if self.sum2:
-            return "sampler_v2 (VN->CN table only) + full_bp_sum fixpoint (count + socket sum per CN)"
         if self.gen2:
             return samp + " + full_bp_small fixpoint (4-bit CN counts)"
         if self.lvl2:
@@ -206,8 +202,6 @@ class Simulator:
         if self.decoder == "sw":
             return E.sw_bp(self.p, adj, ch, self.W, self.max_it, self.init_it, counters=cnt,
                            d_cn_sock=self.d_cn[:nb] if self.ring2 else None)
-        if self.sum2 and not want_rows:
-            return E.full_bp_fixpoint_vn16(self.p, adj, ch, is_term=self.is_term, counters=cnt)
         if self.gen2 and not want_rows:
             return E.full_bp_fixpoint_cn16(self.p, adj, self.d_cn[:nb], ch, is_term=self.is_term, counters=cnt, sockets=self.sock)
         if self.lvl2:
@@ -224,7 +218,7 @@ class Simulator:
                                    out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox" and (self.gen2 or self.lvl2):
             E.sample_philox_cn16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
-                                 out=(self.d_adj[:nb], None if self.sum2 else self.d_cn[:nb], self.d_ch[:nb]))
+                                 out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))
         elif self.rng == "philox" and self.ring2:
             E.sample_philox_sock16(self.p, self.seed, trial_key(self.index, sim, frame0), nb, eps, self.doped,
                                    out=(self.d_adj[:nb], self.d_cn[:nb], self.d_ch[:nb]))

@@ -325,27 +325,6 @@ def full_bp_fixpoint_cn16(p, d_adj16, d_cn16, d_chan, is_term=True, want_erased=
     return {"counters": counters, "rows": None, "erased": erased}
 
 
-def vn16_supported(p):
-    """The (4,8) chain with N <= 512: second-generation sampler (VN -> CN table only) + the count-and-sum decoder."""
-    return bool(lib().scldpc_sample_philox_cn16_supported(C.byref(p))) and bool(lib().scldpc_full_bp_vn16_supported(C.byref(p)))
-
-
-def full_bp_fixpoint_vn16(p, d_adj16, d_chan, is_term=True, want_erased=False, counters=None):
-    """scldpc_full_bp_fixpoint_device_vn16: full_bp_fixpoint's counters from the 2-byte VN -> CN table alone."""
-    _require_gpu()
-    T = d_adj16.shape[0]
-    assert d_adj16.is_cuda and d_adj16.dtype == torch.int16 and d_adj16.is_contiguous()
-    assert d_chan.is_cuda and d_chan.dtype == torch.int32 and d_chan.is_contiguous()
-    assert tuple(d_adj16.shape[1:]) == (p.n, p.dv) and tuple(d_chan.shape) == (T, p.nw)
-    d_cnt = counters if counters is not None else torch.empty((T, NCOUNTERS), dtype=torch.int32, device=d_adj16.device)
-    assert d_cnt.is_cuda and d_cnt.dtype == torch.int32 and d_cnt.is_contiguous() and tuple(d_cnt.shape) == (T, NCOUNTERS)
-    d_er = torch.empty((T, p.nw), dtype=torch.int32, device=d_adj16.device) if want_erased else None
-    check(lib().scldpc_full_bp_fixpoint_device_vn16(C.byref(p), T, d_adj16.data_ptr(), d_chan.data_ptr(), 1 if is_term else 0,
-                                                    d_cnt.data_ptr(), d_er.data_ptr() if d_er is not None else None,
-                                                    _stream_ptr(d_adj16.device)))
-    return {"counters": d_cnt, "rows": None, "erased": d_er}
-
-
 def full_bp_cn16(p, d_adj16, d_cn16, d_chan, max_it=0, is_term=True, want_erased=False, counters=None, sockets=False,
                  rows_cap=0):
     """scldpc_full_bp_device_cn16: decodeBP with its iterations (count, cap, stop tests) from the VN -> CN and CN -> VN

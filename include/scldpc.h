@@ -213,15 +213,6 @@ int scldpc_full_bp_fixpoint_device_sock16(const scldpc_code_params *p, int32_t n
 int scldpc_full_bp_device_sock16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
                                  const uint16_t *d_cn_sock16, const uint32_t *d_chan_bits, int32_t max_it, int32_t is_term,
                                  int32_t *d_counters, uint32_t *d_erased_bits, void *stream);
-/* The fixpoint decoder from the VN -> CN table ALONE (full_bp_sum.hip): a CN keeps count + 8 * (sum of its erased neighbours'
- * sockets) in 16 bits of LDS, so the last erased neighbour of a CN is read out of the word that counted down to one — no
- * CN -> VN table exists, one gather per release instead of two.  Takes dv = 4, dc = 8, vns_pos <= 512 (sockets of 11 bits),
- * at most 65536 VNs and CNs per trial.  Counters as scldpc_full_bp_fixpoint_device (decodeBP, BPF:900-1140, less the
- * iteration count); d_vn_adj16 / d_chan_bits as written by scldpc_sample_philox_device_cn16 (d_cn_adj16 = NULL there). */
-int scldpc_full_bp_vn16_supported(const scldpc_code_params *p);
-int scldpc_full_bp_fixpoint_device_vn16(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
-                                        const uint32_t *d_chan_bits, int32_t is_term, int32_t *d_counters,
-                                        uint32_t *d_erased_bits, void *stream);
 /* decodeBP of the trajectory build (BPT:900-1140) on the same tables: the iterations WITH their rows — per iteration
  * deg_1_iter, the VNs recovered and the position of the first erased VN (BPT:988, 1037-1038, 1051): d_rows int32
  * [ntrials][rows_cap][3]; d_counters[SCLDPC_C_ITERATIONS] says how many rows a trial wrote (rows beyond rows_cap are dropped).

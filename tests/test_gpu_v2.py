@@ -149,61 +149,6 @@ def test_small_decoder_on_reference_fixtures(E, name):
         assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
 
 
-@pytest.mark.parametrize("per_cu", ["5", "4"])
-@pytest.mark.parametrize("L,N,eps,is_term", [(50, 500, 0.48, True), (50, 500, 0.46, False), (50, 512, 0.49, True),
-                                             (16, 200, 0.47, True), (16, 200, 0.30, True), (9, 24, 0.5, False),
-                                             (30, 400, 0.44, False), (10, 10, 0.48, True), (6, 16, 0.9, True),
-                                             (6, 16, 0.05, True), (120, 500, 0.47, True)])
-def test_sum_decoder_equals_flooding_and_small_kernels(E, monkeypatch, L, N, eps, is_term, per_cu):
-    """scldpc_full_bp_fixpoint_device_vn16 (count + socket sum per CN, no CN -> VN table; N <= 512): identical counters and
-    residual patterns to full_bp (flooding) and to the 4-bit kernel, with the narrow queues of five trials per CU and the
-    wider ones of four."""
-    import torch
-    monkeypatch.setenv("SCLDPC_DEBUG_SUM_PER_CU", per_cu)
-    p = E.make_params(4, 8, L, N)
-    assert E.vn16_supported(p)
-    T = 192
-    a, cn, ch = E.sample_philox_cn16(p, 79, 5000, T, eps)
-    ref = E.full_bp(p, a, ch, is_term=is_term, want_erased=True)
-    sm = E.full_bp_fixpoint_cn16(p, a, cn, ch, is_term=is_term, want_erased=True)
-    su = E.full_bp_fixpoint_vn16(p, a, ch, is_term=is_term, want_erased=True)
-    torch.cuda.synchronize()
-    r, s, u = (x["counters"].cpu().numpy() for x in (ref, sm, su))
-    assert (r[:, KEEP] == u[:, KEEP]).all() and (s[:, KEEP] == u[:, KEEP]).all()
-    assert torch.equal(ref["erased"], su["erased"])
-
-
-def test_sum_decoder_refuses_wide_positions(E):
-    p = E.make_params(4, 8, 50, 1000)                        # 4000 sockets per position: the field of 17 bits would carry
-    assert not E.vn16_supported(p)
-    import torch
-    a, _, ch = E.sample_philox_cn16(p, 1, 0, 2, 0.48, want_cn=False)
-    with pytest.raises(E.ScldpcError):
-        E.full_bp_fixpoint_vn16(p, a, ch)
-
-
-@pytest.mark.parametrize("name", golden_names(prefixes=("mid_bpf", "tiny_bpf", "ss2_bpf", "mid_bpt", "tiny_bpt"), uncapped=True))
-def test_sum_decoder_on_reference_fixtures(E, name):
-    """The reference's own graphs and channels (glibc replay on the fixture's seeds): counters incl. the size-2 stopping-set
-    expurgation of the Def_M = 3 ensembles (partner = sum - own socket) and residual patterns."""
-    import torch
-    g = load_golden(name)
-    m = g.meta
-    p = E.make_params(m["dv"], m["dc"], m["L"], m["VNsPos"])
-    if not E.vn16_supported(p):
-        pytest.skip("more than 512 VNs per position")
-    T = min(g.T, 64)
-    adj, ch = E.sample_glibc_trials(p, g["seed"][:T], m["eps"])
-    d_a, d_ch = E.to_device(E.global_to_adj16(p, adj), ch)
-    out = E.full_bp_fixpoint_vn16(p, d_a, d_ch, is_term=bool(m["is_term"]), want_erased=True)
-    torch.cuda.synchronize()
-    c = out["counters"].cpu().numpy()
-    assert (c[:, 0] == g["ne"][:T]).all() and (c[:, 1] == g["be"][:T]).all()
-    assert (c[:, 2] == g["ee"][:T]).all() and (c[:, 3] == g["bee"][:T]).all() and (c[:, 7] == g["nch"][:T]).all()
-    if g.has("erased"):
-        assert (E.unpack_bits(out["erased"].cpu().numpy(), p.n) == g["erased"][:T]).all()
-
-
 # ---- the same decoder walked one flooding iteration per barrier round (scldpc_full_bp_device_cn16) ------------------------
 @pytest.mark.parametrize("L,N,eps,is_term,caps", [
     (50, 1000, 0.48, True, (0, 1, 2, 3, 40, 150, 233, 400)), (50, 1000, 0.45, True, (0, 25, 90)),
