@@ -44,15 +44,17 @@ namespace {
 using namespace scldpc_dev;
 
 constexpr int kGenThreads = 1024, kDecThreads = 256, kMaxDoped = 32, kMaxL = 256;
-constexpr int kQCap = 2048;                         // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
+constexpr int kQCap = 512;                          // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
+constexpr int kFrozen = 8;                          // slots of the frozen-position rings in the blob (> 2dv - 1 - (dv - 1) positions)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
-    size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, poscnt, gkey, wlist, tslg, counters, total;
+    size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, fz_cnt, fz_s, poscnt, gkey, wlist, tslg, counters, total;
     int wpp;                // 32-bit words of S bits per position
     int Cw;                 // 32-bit words of count nibbles per CN position
     int R, RV;              // ring slots: CN positions / VN positions the decoder keeps in LDS
+    int Lp;                 // L rounded up to four (per-slot counts in LDS)
 };
 
 struct Args {
@@ -464,7 +466,11 @@ __global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))
 // ==================================================== DECODE =============================================================
 // 256 threads per stream; the window's state in LDS (sw_ring.hip's layout, here for the classical window on a circular
 // buffer with unlimited iterations per position).  Ring slots are addressed relative to the decoder's position: every
-// position touched while it stands at `pos` lies within [pos - 2dv + 1, pos + W + dv - 2], less than a ring apart.
+// position a release can touch while it stands at `pos` lies within [pos - dv + 1, pos + W + dv - 2], less than a ring apart.
+// What lies further left is frozen: VN position pos - dv + 1 is decided in this step and CN position pos - dv + 1 is out of
+// reach of the next window's VNs, so both leave the LDS at the end of the step for a small ring in the blob, where the
+// size-2 stopping-set test of position pos - 2dv + 1 reads them (only when that position still holds erasures).  That keeps
+// the LDS at W + 2dv - 2 CN positions and W + dv - 1 VN positions: 50 KB at N = 5000, W = 20 — three streams per CU.
 template <int DV>
 __device__ __forceinline__ void stream_dec_body(const Args &a)
 {
@@ -477,7 +483,7 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
     uint32_t *Sr = cnt + R * Cw;                                        // [RV][wpp] S bits
     uint32_t *q0 = Sr + RV * wpp, *q1 = q0 + kQCap;                     // frontier queues: [CN position offset + 2dv | CN]
     int *pos_cnt = reinterpret_cast<int *>(q1 + kQCap);                 // [L] erased VNs per buffer slot (position % L)
-    int *scal = pos_cnt + kMaxL;
+    int *scal = pos_cnt + a.lay.Lp;
 
     const int tid = threadIdx.x, lane = tid & 63;
     char *st = a.state + (size_t)blockIdx.x * a.lay.total;
@@ -486,6 +492,8 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
     const uint32_t *Sb = reinterpret_cast<const uint32_t *>(st + a.lay.sbits);
     uint32_t *ring_cnt = reinterpret_cast<uint32_t *>(st + a.lay.ring_cnt);
     uint32_t *ring_s = reinterpret_cast<uint32_t *>(st + a.lay.ring_s);
+    uint32_t *fz_cnt = reinterpret_cast<uint32_t *>(st + a.lay.fz_cnt);            // [kFrozen][Cw] counts of frozen CN positions, by position % kFrozen
+    uint32_t *fz_s = reinterpret_cast<uint32_t *>(st + a.lay.fz_s);                // [kFrozen][wpp] S bits of frozen VN positions
     int *pos_cnt_g = reinterpret_cast<int *>(st + a.lay.poscnt);
     long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
 
@@ -708,11 +716,12 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
         // size-2 stopping-set expurgation of position pos - 2dv + 1 (get_deg_two_ss, BPF:1227-1283, 1485-1497): an erased VN
         // whose dv CNs all hold exactly two erased neighbours, the other one the same VN of the same position each time
         if (pe >= 0) {
-            const int de = -(2 * DV - 1), sb = sslot(de), ls = lslot(de);
+            const int de = -(2 * DV - 1), ls = lslot(de);
+            const uint32_t *fs = fz_s + (size_t)(pe & (kFrozen - 1)) * wpp;     // frozen since the end of step pe + dv - 1
             int mine = 0;
             if (pos_cnt[ls] > 0) {
                 for (int w = tid; w < wpp; w += kThreads) {
-                    uint32_t x = Sr[sb + w];
+                    uint32_t x = fs[w];
                     while (x) {
                         const int b = __ffs((int)x) - 1;
                         x &= x - 1;
@@ -721,7 +730,8 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
                         const uint32_t l[4] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16};
                         bool pair = true;
 #pragma unroll
-                        for (int i = 0; i < DV; i++) pair = pair && ((cnt[cslot(de + i) + (l[i] >> 3)] >> ((l[i] & 7) * 4)) & 15u) == 2u;
+                        for (int i = 0; i < DV; i++)
+                            pair = pair && ((fz_cnt[(size_t)((pe + i) & (kFrozen - 1)) * Cw + (l[i] >> 3)] >> ((l[i] & 7) * 4)) & 15u) == 2u;
                         int partner = -1;
                         for (int i = 0; i < DV && pair; i++) {            // the other erased neighbour, if it is in position pe
                             const uint16_t *row = cnsock + ((size_t)lslot(de + i) * C + l[i]) * dc;
@@ -729,7 +739,7 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
                             for (int k = 0; k < dc; k++) {
                                 const uint32_t s = row[k];
                                 const int i2 = (int)(s % DV), t2 = (int)(s / DV);
-                                if (i2 == i && t2 != t && ((Sr[sb + (t2 >> 5)] >> (t2 & 31)) & 1u)) other = t2;
+                                if (i2 == i && t2 != t && ((fs[t2 >> 5] >> (t2 & 31)) & 1u)) other = t2;
                             }
                             if (other < 0 || (i > 0 && other != partner)) pair = false;
                             partner = other;
@@ -751,6 +761,13 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
             tr[0] = (int32_t)pos; tr[1] = nep;
             tr[2] = (int32_t)acc[C_NE]; tr[3] = (int32_t)acc[C_BE]; tr[4] = (int32_t)acc[C_EE]; tr[5] = (int32_t)acc[C_BEE];
             tr[6] = (int32_t)acc[C_GB]; tr[7] = (int32_t)acc[C_GBL]; tr[8] = (int32_t)acc[C_GBE]; tr[9] = (int32_t)acc[C_GBLE];
+        }
+        // VN position pos - ms (decided above) and CN position pos - ms (its VNs are all frozen now) leave the LDS
+        if (pd >= 0) {
+            const int cs = cslot(-ms), sb = sslot(-ms);
+            uint32_t *gc = fz_cnt + (size_t)(pd & (kFrozen - 1)) * Cw, *gs = fz_s + (size_t)(pd & (kFrozen - 1)) * wpp;
+            for (int i = tid; i < Cw; i += kThreads) gc[i] = cnt[cs + i];
+            for (int w = tid; w < wpp; w += kThreads) gs[w] = Sr[sb + w];
         }
         __syncthreads();
         STAMP(3);
@@ -789,14 +806,17 @@ int make_state_layout(const scldpc_code_params *p, int W, StateLayout *lay)
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     lay->wpp = (int)((V + 31) / 32);
     lay->Cw = (int)((C + 7) / 8);
-    lay->R = W + 3 * p->dv - 2;                     // CN positions pos - 2dv + 1 .. pos + W + dv - 2
-    lay->RV = W + 2 * p->dv - 1;                    // VN positions pos - 2dv + 1 .. pos + W - 1
+    lay->R = W + 2 * p->dv - 2;                     // CN positions pos - dv + 1 .. pos + W + dv - 2
+    lay->RV = W + p->dv - 1;                        // VN positions pos - dv + 1 .. pos + W - 1
+    lay->Lp = (p->L + 3) & ~3;
     lay->adj = take(L * V * dv * 2);
     lay->cnsock = take(L * S * 2);
     lay->inter = take(dv * S * 2);
     lay->sbits = take(L * lay->wpp * 4);
     lay->ring_cnt = take((size_t)lay->R * lay->Cw * 4);
     lay->ring_s = take((size_t)lay->RV * lay->wpp * 4);
+    lay->fz_cnt = take((size_t)kFrozen * lay->Cw * 4);
+    lay->fz_s = take((size_t)kFrozen * lay->wpp * 4);
     lay->poscnt = take(L * 4);
     lay->gkey = take(S * 8); lay->wlist = take(S * 8);
     lay->tslg = take(S);                            // arrival slots of the 16-bit-counter fallback ranking
@@ -807,7 +827,7 @@ int make_state_layout(const scldpc_code_params *p, int W, StateLayout *lay)
 
 size_t dec_lds_bytes(const StateLayout &lay)
 {
-    return 4u * ((size_t)16 + (size_t)lay.R * lay.Cw + (size_t)lay.RV * lay.wpp + 2 * kQCap + kMaxL + S_NSCAL);
+    return 4u * ((size_t)16 + (size_t)lay.R * lay.Cw + (size_t)lay.RV * lay.wpp + 2 * kQCap + lay.Lp + S_NSCAL);
 }
 
 int check_stream(const scldpc_code_params *p, int W, const char *who)

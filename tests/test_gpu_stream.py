@@ -146,3 +146,54 @@ def test_stream_kernel_on_the_reference_stream_equals_the_reference(E, path):
     assert (rows == z["rows"][:P]).all(), np.argwhere(rows != z["rows"][:P])[:3]
     c = cnt[0].cpu().numpy()
     assert c[:8].tolist() == z["rows"][P - 1][2:].tolist() and c[8] == P and c[9] == G
+
+
+# ---- many short streams against few long ones -----------------------------------------------------------
+def _stream_pieces(E, p, nstreams, npieces, piece, seed, eps, doped, stream0, W=20):
+    """Block errors and blocks after expurgation (counters 3, 7) of every (stream, piece of `piece` positions)."""
+    import torch
+    st = E.Streams(p, nstreams, seed=seed, eps=eps, W=W, doped=doped, stream0=stream0)
+    prev = torch.zeros_like(st.counters)
+    out = []
+    for _ in range(npieces):
+        c, _ = st.run(piece)
+        out.append((c - prev)[:, [3, 7]].cpu().numpy())
+        prev = c.clone()
+    return np.stack(out, axis=1)                                # [stream][piece][errors, blocks]
+
+
+def test_many_short_doped_streams_estimate_the_same_bler_as_few_long_ones(E):
+    """The reference's streaming experiment is ONE long stream (main_streaming, BPF:1934-2054); `sw --streams S` sums S
+    independent streams advanced in lock step.  With doping that decouples the chain (dv - 1 = 3 consecutive known positions
+    per period: doped {10, 11, 12}) a stream is a sequence of independent, identically distributed segments, the first —
+    which starts from the known left end — included, so 512 streams x 2000 positions and 4 streams x 256 000 positions see
+    the same process: their BLERs agree within the spread of 2000-position samples (profiles/r03_stream_equivalence.txt has
+    the same at other eps: z = +0.6 at eps = 0.48).  Tolerance: |z| < 4 on >= 200 block errors each."""
+    p = E.make_params(4, 8, 50, 1000)
+    a = _stream_pieces(E, p, 512, 1, 2000, 11, 0.482, (10, 11, 12), 0).reshape(-1, 2).astype(np.float64)
+    b = _stream_pieces(E, p, 4, 128, 2000, 11, 0.482, (10, 11, 12), 1 << 20).reshape(-1, 2).astype(np.float64)
+
+    def est(s):
+        bler = s[:, 0].sum() / s[:, 1].sum()
+        return bler, np.std(s[:, 0] - bler * s[:, 1], ddof=1) * np.sqrt(len(s)) / s[:, 1].sum()
+    (ba, sa), (bb, sb) = est(a), est(b)
+    assert a[:, 0].sum() >= 200 and b[:, 0].sum() >= 200, (a[:, 0].sum(), b[:, 0].sum())
+    assert abs(ba - bb) < 4.0 * np.hypot(sa, sb), (ba, sa, bb, sb)
+
+
+def test_an_undoped_stream_that_failed_keeps_failing(E):
+    """Without doping the two estimators are NOT the same experiment, and no burn-in repairs it: once a window has lost its
+    known left end every later block is in error (measured: share 1.0), so the reference's single-stream figure is
+    errors / (time to the first failure + errors) — a property of ONE stream.  The driver therefore documents `--streams 1`
+    (with `--rng glibc`: the reference's run row for row) for undoped ensembles and many streams for doped ones
+    (INTEGRATION.md §streaming).  Here: 8 undoped streams near threshold, 40 pieces of 500 positions; every stream that
+    fails does so for good."""
+    p = E.make_params(4, 8, 50, 1000)
+    s = _stream_pieces(E, p, 8, 40, 500, 5, 0.455, (), 0)
+    bad = s[:, :, 0] > 0                                        # [stream][piece]
+    assert bad.any()
+    for k in range(bad.shape[0]):
+        if bad[k].any():
+            first = int(np.argmax(bad[k]))
+            assert bad[k, first:].all(), (k, first, bad[k].astype(int))
+            assert (s[k, first + 1:, 0] == s[k, first + 1:, 1]).all()       # every later block of the stream is in error
