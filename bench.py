@@ -587,10 +587,10 @@ def run_c5(a, E, dev, rank, world, dist, fence, finish):
     L_BUF, N_POS, W, DOPED, CHUNK = 50, 5000, 20, (10, 11, 12), 16
     EPS = 0.485 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_BUF, N_POS)
-    NS = a.batch or 4096                              # two 256-thread decode workgroups per CU in flight; 8 rounds of them per launch
+    NS = a.batch or 6144                              # three 256-thread decode workgroups per CU in flight: a half of 3072 streams is four rounds of them
     # The streams are independent, so they are run as two halves on two HIP streams: the generation launches of one half
     # (vector / LDS work, 16 waves per workgroup) overlap the decode launches of the other (waits on row gathers, 4 waves per
-    # workgroup) — one of each fits a CU's LDS together (75 + 71 KB).  --no-overlap: one set, one stream.
+    # workgroup) — they share a CU's LDS (75 KB / 50 KB per workgroup).  --no-overlap: one set, one stream.
     halves = 1 if a.no_overlap or NS < 2 else 2
     sizes = [NS - NS // 2, NS // 2][:halves] if halves == 2 else [NS]
     hip_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(halves - 1)]
