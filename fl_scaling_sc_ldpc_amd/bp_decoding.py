@@ -575,10 +575,14 @@ def run_streaming(index, W, doped, opts):
                        stream0=(sim * world + rank) * opts.streams, device=device)
         while True:
             cnt, _ = st.run(opts.chunk)
-            tot = cnt[:, :8].sum(dim=0)
+            # (column 9 = positions generated; negative = the stream was marked unusable, include/scldpc.h)
+            tot = torch.cat([cnt[:, :8].sum(dim=0), (cnt[:, 9] < 0).sum().reshape(1)])
             if dist is not None:
-                dist.all_reduce(tot)                    # the only exchange: eight int64 per chunk
+                dist.all_reduce(tot)                    # the only exchange: nine int64 per chunk
             tot = tot.cpu().numpy()
+            if tot[8] > 0:                              # every rank sees the same sum and leaves together
+                raise SystemExit("sw: %d stream(s) marked unusable by the generation kernel (a ranking bucket overflowed)" % tot[8])
+            tot = tot[:8]
             if tot[3] >= opts.max_blocks_err or tot[7] >= opts.max_blocks:
                 break
         if rank == 0:

@@ -47,7 +47,7 @@ constexpr int kGenThreads = 1024, kDecThreads = 256, kMaxDoped = 32, kMaxL = 256
 constexpr int kQCap = 512;                          // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
 constexpr int kFrozen = 8;                          // slots of the frozen-position rings in the blob (> 2dv - 1 - (dv - 1) positions)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
-enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_NSCAL = 16 };
+enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_BAD = 11, S_NSCAL = 16 };
 
 struct StateLayout {        // byte offsets inside one stream's blob
     size_t adj, cnsock, inter, sbits, ring_cnt, ring_s, fz_cnt, fz_s, poscnt, gkey, wlist, tslg, counters, total;
@@ -61,6 +61,7 @@ struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
     int gen_ahead;              // GENERATE: until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
     int force_wide;             // diagnostics / tests: rank every position by the 16-bit-counter fallback
+    int wlcap;                  // GENERATE, fused ranking: entries of the straddlers' worklist in LDS (<= 2 * kGenThreads)
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
@@ -91,17 +92,18 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
 }
 
 // =================================================== GENERATE ============================================================
-// ROWS <= 4 (at most 4096 counter words, N <= 1024 at (4,8)): the LDS part is 34 KB, so two workgroups fit a CU if the
-// compiler keeps to 64 VGPRs and 80 SGPRs (see full_bp.hip).  Larger ensembles need more LDS for the counters.
-template <int ROWS>
+// LDS: [scan scratch | scalars | hist: a.nb / 2 words | aux].  FUSED (at most 8 Philox calls per thread, everything within a
+// CU's LDS): aux = the CN-row stage (S sockets, 2 bytes each) + the straddlers' worklist; otherwise aux = the fill counters of
+// cn_rows and the stage lies over hist.  75-80 KB at N = 5000: two workgroups per CU (64 VGPRs, 72 SGPRs).
+template <bool FUSED>
 __device__ __forceinline__ void stream_gen_body(const Args &a)
 {
     constexpr int kThreads = kGenThreads, kWaves = kThreads / 64;
     extern __shared__ uint32_t lds[];
     uint32_t *wsum = lds;                                               // scan scratch
     int *scal = reinterpret_cast<int *>(wsum + 32);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // nb words of four nibble-wide bucket counters (ranking); then the CN-row stage
-    uint8_t *tsl = reinterpret_cast<uint8_t *>(hist + a.nb);             // [S/2] arrival slots (nibbles) of the sockets' keys; then the CN fill counters
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // a.nb / 2 words: four nibble-wide (fused) or two 16-bit (wide) bucket counters each
+    uint32_t *aux = hist + a.nb / 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, wpp = a.lay.wpp;
@@ -121,6 +123,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     __syncthreads();
     const long long pos = cnt64[C_POS];
     long long gen = cnt64[C_GEN];
+    if (gen < 0) return;                                    // a stream marked unusable (see rank_wide) stays so
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
     // Ranking with 16-bit bucket counters (a.nb buckets, two per word, arrival slots as bytes in the blob): the fallback of
@@ -151,39 +154,31 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                 }
             }
         }
-        if (crowded >= 256u) __builtin_trap();              // arrival slots are kept in a byte (a bucket holds 1-4 keys on average)
+        if (crowded >= 256u) scal[S_BAD] = 1;               // arrival slots are kept in a byte (a bucket holds 1-4 keys on average): the stream is
+                                                            // marked unusable (gen < 0) instead of being ranked wrongly — 256 of 2^16 keys in one of >= 1024 buckets
         __syncthreads();
         STAMP(7);
-        // wave w scans buckets [w, w+1) * nb/16 = ROWS * 32 words of two counters: exclusive prefix inside the chunk, then
-        // (second barrier) plus the chunks before it — every bucket's first rank, 16 bits
-        constexpr int R2 = ROWS >= 2 ? ROWS / 2 : 1;
-        const bool on = ROWS >= 2 || lane < 32;
-        const int w0 = wave * (ROWS * 32) + lane;
+        // wave w scans words [w, w + 1) * nb / 32 of two counters, 64 at a time: exclusive prefix inside the chunk, then (second
+        // barrier) plus the chunks before it — every bucket's first rank, 16 bits
         {
-            uint32_t v[R2], ps[R2], inc[R2];
-#pragma unroll
-            for (int r = 0; r < R2; r++) { v[r] = on ? hist[w0 + r * 64] : 0u; ps[r] = (v[r] & 0xFFFFu) + (v[r] >> 16); }
-#pragma unroll
-            for (int r = 0; r < R2; r++) inc[r] = wave_inclusive_scan(ps[r]);
+            const int cw = a.nb / 2 / kWaves, w0 = wave * cw;
             uint32_t carry = 0;
-#pragma unroll
-            for (int r = 0; r < R2; r++) {
-                const uint32_t ex = carry + inc[r] - ps[r];
-                if (on) hist[w0 + r * 64] = (ex & 0xFFFFu) | ((ex + (v[r] & 0xFFFFu)) << 16);
-                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc[r], 63);
+            for (int i0 = 0; i0 < cw; i0 += 64) {
+                const bool on = i0 + lane < cw;
+                const uint32_t v = on ? hist[w0 + i0 + lane] : 0u, ps = (v & 0xFFFFu) + (v >> 16);
+                const uint32_t inc = wave_inclusive_scan(ps), ex = carry + inc - ps;
+                if (on) hist[w0 + i0 + lane] = (ex & 0xFFFFu) | ((ex + (v & 0xFFFFu)) << 16);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             }
             if (lane == 0) wsum[wave] = carry;
-        }
-        __syncthreads();
-        {
+            __syncthreads();
             const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
-            const uint32_t inc = wave_inclusive_scan(t);
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(inc - t), wave);
-#pragma unroll
-            for (int r = 0; r < R2; r++)
-                if (on) {                                   // (a first rank of 65536 = S wraps to 0: see bucket_end)
-                    const uint32_t w = hist[w0 + r * 64];
-                    hist[w0 + r * 64] = ((w + base) & 0xFFFFu) | (((w >> 16) + base) << 16);
+            const uint32_t tinc = wave_inclusive_scan(t);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(tinc - t), wave);
+            for (int i0 = 0; i0 < cw; i0 += 64)
+                if (i0 + lane < cw) {                       // (a first rank of 65536 = S wraps to 0: see bucket_end)
+                    const uint32_t w = hist[w0 + i0 + lane];
+                    hist[w0 + i0 + lane] = ((w + base) & 0xFFFFu) | (((w >> 16) + base) << 16);
                 }
         }
         __syncthreads();
@@ -251,56 +246,71 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     };
 
 
-    // Round 3: four nibble-wide counters per word plus the word's 16-bit first rank (sampler_v2.hip's histogram) — four
-    // times as many buckets in twice the LDS, so a quarter of the keys sit in buckets that straddle two CNs (3.8 % at
-    // N = 5000 instead of 15 %) and a quarter of the straddlers' records travel through the blob.  The arrival slots are
-    // nibbles too (one 16-bit store per Philox call).  Returns false (for every thread) when a bucket met a sixteenth key.
-    auto rank_nib = [&](long long cpos) -> bool {
-        const int ncalls = (S + 3) / 4, nbw = a.nb, bshift = a.shift - 2;
-        uint16_t *tsl16 = reinterpret_cast<uint16_t *>(tsl);
+    // Round 3, FUSED: ranking and CN rows in one pass over LDS.  Four nibble-wide counters per word (2 * a.nb buckets) plus the
+    // word's 16-bit first rank; a key's arrival slot in its bucket stays in a register of the thread that drew it (one nibble
+    // per key).  first rank + arrival slot is a rank slot of the key's own, so the socket goes straight to stage[rank slot] —
+    // the CN -> socket rows, no fill counters — and, where the bucket lies inside one CN, CN = first rank / dc goes to the
+    // socket -> CN row.  Keys of buckets that straddle two CNs (7.6 % at N = 5000) are listed; each is ranked against its bucket
+    // mates, whose keys are drawn again from their sockets (Philox is pure arithmetic), and moved to stage[first rank + rank].
+    // No step goes through global memory.  Returns false (for every thread, nothing usable written) when a bucket met a
+    // sixteenth key or the list overflowed: the caller ranks the position again with rank_wide + cn_rows.
+    auto rank_fused = [&](long long cpos) -> bool {
+        const int ncalls = (S + 3) / 4, nbw = a.nb / 2, bshift = a.shift - 1;
+        uint16_t *stage = reinterpret_cast<uint16_t *>(aux), *wl = stage + ((S + 1) & ~1);
         uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
         asm volatile("" : "+s"(k_lo), "+s"(k_hi));          // (no Philox round keys hoisted out of the position loop and spilled)
         for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
         if (tid == 0) { scal[S_WL] = 0; scal[S_OVF] = 0; }
         __syncthreads();
-        uint32_t crowded = 0;
-        for (int q = tid; q < ncalls; q += kThreads) {
-            uint32_t r[4], pk = 0;
-            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
+        // the arrival slots (a nibble each) of the keys this thread draws: call tid + k * kThreads in bits 16 (k & 1) of pk[k >> 1];
+        // the loops over k are not unrolled (their trip count is uniform: the selects are scalar), or eight inlined Philox
+        // bodies in flight spill half a kilobyte per lane
+        uint32_t pk[4] = {0, 0, 0, 0}, crowded = 0;
+#pragma unroll 1
+        for (int k = 0; k * kThreads < ncalls; k++) {
+            const int q = tid + k * kThreads;
+            uint32_t mine = 0;
+            if (q < ncalls) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (q * 4 + u < S) {
-                    const uint32_t b = r[u] >> bshift, sh = (b & 3u) * 4u;
-                    const uint32_t sl = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 15u;
-                    pk |= sl << (4 * u);
-                    crowded |= sl + 1u;
+                for (int u = 0; u < 4; u++) {
+                    if (q * 4 + u < S) {
+                        const uint32_t b = r[u] >> bshift, sh = (b & 3u) * 4u;
+                        const uint32_t sl = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 15u;
+                        mine |= sl << (4 * u);
+                        crowded |= sl + 1u;
+                    }
                 }
             }
-            tsl16[q] = (uint16_t)pk;
+            mine <<= (k & 1) * 16;
+#pragma unroll
+            for (int h = 0; h < 4; h++) pk[h] |= (k >> 1) == h ? mine : 0u;
         }
         if (crowded & 16u) scal[S_OVF] = 1;                 // a nibble wrapped
         __syncthreads();
         STAMP(7);
         if (scal[S_OVF] || a.force_wide) { __syncthreads(); return false; }
-        // exclusive scan of the bucket counts: thread t owns words t*ROWS .. t*ROWS+ROWS-1; the word's first rank goes into
-        // its high half
+        // exclusive scan of the bucket counts, bank-conflict free: wave w owns words [w, w + 1) * nbw / 16, its lanes take
+        // them 64 at a time; the word's first rank goes into its high half, the waves before it are added in a second pass
         {
-            uint32_t x[ROWS], v[ROWS], tot = 0;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                x[r] = hist[tid * ROWS + r];
-                const uint32_t sb = (x[r] & 0x0F0Fu) + ((x[r] >> 4) & 0x0F0Fu);
-                v[r] = (sb + (sb >> 8)) & 0xFFu;
-                tot += v[r];
+            const int cw = nbw / kWaves, w0 = wave * cw;
+            uint32_t carry = 0;
+            for (int i0 = 0; i0 < cw; i0 += 64) {
+                const bool on = i0 + lane < cw;
+                const uint32_t x = on ? hist[w0 + i0 + lane] : 0u;
+                const uint32_t sb = (x & 0x0F0Fu) + ((x >> 4) & 0x0F0Fu), ps = (sb + (sb >> 8)) & 0xFFu;
+                const uint32_t inc = wave_inclusive_scan(ps);
+                if (on) hist[w0 + i0 + lane] = x | ((carry + inc - ps) << 16);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             }
-            const uint32_t inc = wave_inclusive_scan(tot);
-            if (lane == 63) wsum[wave] = inc;
+            if (lane == 0) wsum[wave] = carry;
             __syncthreads();
-            const uint32_t wt = lane < kWaves ? wsum[lane] : 0u;
-            const uint32_t winc = wave_inclusive_scan(wt);
-            uint32_t pre = inc - tot + (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) { hist[tid * ROWS + r] = x[r] | (pre << 16); pre += v[r]; }
+            const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t tinc = wave_inclusive_scan(t);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(tinc - t), wave) << 16;
+            for (int i0 = 0; i0 < cw; i0 += 64)
+                if (i0 + lane < cw) hist[w0 + i0 + lane] += base;
         }
         __syncthreads();
         STAMP(8);
@@ -316,70 +326,99 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
             cnt = (x >> sh) & 0xFu;
         };
         uint16_t *dst = inter + (size_t)(cpos % dv) * S;
-        for (int q = tid; q < ncalls; q += kThreads) {
-            uint32_t r[4];
-            philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
-            const uint32_t slots = tsl16[q];
-            uint32_t c4[4] = {0, 0, 0, 0};                  // (a straddler's entry is written by the third pass)
+        bool spill = false;
+#pragma unroll 1
+        for (int k = 0; k * kThreads < ncalls; k++) {
+            const int q = tid + k * kThreads;
+            uint32_t slots = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int s = q * 4 + u;
-                if (s >= S) continue;
-                uint32_t g0, cnt;
-                bucket_of(r[u], g0, cnt);
-                if (!straddles(g0, cnt)) { c4[u] = cn_of(g0); continue; }
-                gkey[g0 + ((slots >> (4 * u)) & 15u)] = make_uint2(r[u], (uint32_t)s);
-                wlist[atomicAdd(&scal[S_WL], 1)] = make_uint2(r[u], (uint32_t)s | (g0 << 16));
+            for (int h = 0; h < 4; h++) slots |= (k >> 1) == h ? pk[h] : 0u;
+            slots >>= (k & 1) * 16;
+            if (q < ncalls) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
+                uint32_t c4[4] = {0, 0, 0, 0};              // (a straddler's entry is written by the pass below)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int s = q * 4 + u;
+                    if (s >= S) continue;
+                    uint32_t g0, cnt;
+                    bucket_of(r[u], g0, cnt);
+                    stage[g0 + ((slots >> (4 * u)) & 15u)] = (uint16_t)s;
+                    if (!straddles(g0, cnt)) { c4[u] = cn_of(g0); continue; }
+                    const int at = atomicAdd(&scal[S_WL], 1);
+                    if (at < a.wlcap) wl[at] = (uint16_t)s; else spill = true;
+                }
+                if (q * 4 + 3 < S && (S & 3) == 0) {
+                    *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
+                } else {
+                    for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
+                }
             }
-            if (q * 4 + 3 < S && (S & 3) == 0) {
-                *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
-            } else {
-                for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
+        }
+        if (spill) scal[S_OVF] = 1;
+        __syncthreads();
+        STAMP(9);
+        if (scal[S_OVF]) { __syncthreads(); return false; }
+        // the straddlers, one per lane, two rounds at most (wlcap <= 2 * kThreads): rank among the bucket mates, then — when
+        // every lane has read its mates — the move to the rank's own slot
+        {
+            const int nwl = scal[S_WL];
+            uint32_t res[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // socket | rank << 16
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int w = tid + h * kThreads;
+                if (w >= nwl) continue;
+                const uint32_t s = wl[w];
+                uint32_t r[4];
+                philox4x32_10(s >> 2, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
+                const uint32_t key = (s & 2u) ? ((s & 1u) ? r[3] : r[2]) : ((s & 1u) ? r[1] : r[0]);
+                uint32_t g0, cnt;
+                bucket_of(key, g0, cnt);
+                uint32_t rank = g0;
+                for (uint32_t m = 0; m < cnt; m++) {        // a key's own socket compares false with itself
+                    const uint32_t s2 = stage[g0 + m];
+                    uint32_t r2[4];
+                    philox4x32_10(s2 >> 2, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r2);
+                    const uint32_t k2 = (s2 & 2u) ? ((s2 & 1u) ? r2[3] : r2[2]) : ((s2 & 1u) ? r2[1] : r2[0]);
+                    rank += (k2 < key) || (k2 == key && s2 < s);
+                }
+                res[h] = s | (rank << 16);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (res[h] == 0xFFFFFFFFu) continue;
+                const uint32_t s = res[h] & 0xFFFFu, rank = res[h] >> 16;
+                stage[rank] = (uint16_t)s;
+                dst[s] = cn_of(rank);
             }
         }
         __syncthreads();
-        STAMP(9);
+        STAMP(4);
+        // the CN -> socket rows of the position, whole
         {
-            const int nwl = scal[S_WL];
-            for (int w = tid; w < nwl; w += kThreads) {
-                const uint2 e = wlist[w];
-                const uint32_t k = e.x, s = e.y & 0xFFFFu;
-                uint32_t g0, cnt;
-                bucket_of(k, g0, cnt);
-                uint32_t rank = g0;                         // the mates' records, four at a time; a key's own compares false
-                for (uint32_t g = g0; g < g0 + cnt; g += 4) {
-                    uint2 m[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) m[i] = g + i < g0 + cnt ? gkey[g + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
-                }
-                dst[s] = cn_of(rank);
+            uint16_t *rows = cnsock + (size_t)(cpos % L) * S;
+            if ((S & 1) == 0) {
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(rows);
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage);
+                for (int w = tid; w < S / 2; w += kThreads) d32[w] = s32[w];
+            } else {
+                for (int w = tid; w < S; w += kThreads) rows[w] = stage[w];
             }
         }
         __syncthreads();
         return true;
     };
 
-    auto rank_position = [&](long long cpos) {
-        if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
-            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
-            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
-            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
-            __syncthreads();
-            return;
-        }
-        if (!rank_nib(cpos)) rank_wide(cpos);
-    };
-
-    // ---- the CN -> socket rows of CN position cpos from its finished socket -> CN row: the ranking's LDS is free now, so
-    //      the rows are staged there (a nibble-wide fill counter per CN hands out the dc places of a row: which place a
-    //      socket gets is immaterial, consumers treat a row as a set) and written out whole, `chunk` CNs at a time -------
+    // ---- the CN -> socket rows of CN position cpos from its finished socket -> CN row (the fallback ranking, the same-input
+    //      mode): staged in LDS (a nibble-wide fill counter per CN hands out the dc places of a row: which place a socket
+    //      gets is immaterial, consumers treat a row as a set) and written out whole, `chunk` CNs at a time -------------------
     auto cn_rows = [&](long long cpos) {
         const uint16_t *row = inter + (size_t)(cpos % dv) * S;
-        uint16_t *stage = reinterpret_cast<uint16_t *>(hist);
-        uint32_t *fill = reinterpret_cast<uint32_t *>(tsl);
-        const int chunk = std::min(C, (2 * a.nb / a.dc) & ~7);            // CNs per pass: the stage holds 2 * a.nb sockets (2 bytes each)
+        uint16_t *stage = reinterpret_cast<uint16_t *>(FUSED ? aux : hist);
+        uint32_t *fill = FUSED ? hist : aux;
+        const int chunk = FUSED ? C : std::min(C, (a.nb / a.dc) & ~7);         // CNs per pass: the stage over hist holds a.nb sockets
         uint16_t *dst = cnsock + (size_t)(cpos % L) * C * a.dc;
         for (int c0 = 0; c0 < C; c0 += chunk) {
             const int c1 = std::min(C, c0 + chunk);
@@ -405,11 +444,29 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         }
     };
 
+    // socket -> CN row and CN -> socket rows of CN position cpos (every lambda has ONE call site: the kernel holds one copy of
+    // each ranking, and what is live across them fits the 64 VGPRs two workgroups per CU allow)
+    auto rank_position = [&](long long cpos) {
+        bool rows_done = false;
+        if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
+            const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
+            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
+            __syncthreads();
+        } else {
+            if constexpr (FUSED) rows_done = rank_fused(cpos);
+            if (!rows_done) rank_wide(cpos);
+        }
+        if (!rows_done) {
+            STAMP(4);
+            cn_rows(cpos);
+        }
+    };
+
     // ---- generate_stream_pos(g) (BPF:1927-1932): CN position g+dv-1 ranked, VN position g wired, its channel drawn ----------
     auto generate = [&](long long g) {
         rank_position(g + dv - 1);
-        STAMP(4);
-        cn_rows(g + dv - 1);
+        if (g < 0) return;                                  // a new stream's CN positions 0 .. dv-2 (initialize_arrays_circular, BPF:1808-1813)
         const int slot = (int)(g % L);
         const bool doped = position_is_doped(a, g);
         uint32_t c_lo = a.seed_lo, c_hi = a.seed_hi;
@@ -445,22 +502,24 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         STAMP(6);
     };
 
-    if (gen == 0 && pos == 0) {                             // a new stream (BPF:2003-2012)
-        for (int c = 0; c < dv - 1; c++) { rank_position(c); cn_rows(c); }       // initialize_arrays_circular (BPF:1808-1813)
-        for (; gen < L / 2; gen++) generate(gen);
-    }
-    for (; gen < pos + L / 2 + a.gen_ahead; gen++) generate(gen);   // what the next DECODE launches will have consumed (BPF:2036-2045)
+    // a new stream starts with its first dv - 1 CN positions and L/2 positions (BPF:2003-2012); then what the next DECODE
+    // launches will have consumed (BPF:2036-2045)
+    const long long target = pos + L / 2 + a.gen_ahead;
+    for (long long g = (gen == 0 && pos == 0) ? -(long long)(dv - 1) : gen; g < target; g++) generate(g);
+    gen = gen > target ? gen : target;
     STAMP_FLUSH();
+    __syncthreads();
+    if (scal[S_BAD]) gen = -1;
     if (tid == 0) {
         cnt64[C_GEN] = gen;
         if (a.counters_out) a.counters_out[(size_t)blockIdx.x * 10 + 9] = gen;
     }
 }
 
-template <int ROWS>
+template <bool FUSED>
 __global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_gen_kernel(const Args a)
 {
-    stream_gen_body<ROWS>(a);
+    stream_gen_body<FUSED>(a);
 }
 
 // ==================================================== DECODE =============================================================
@@ -499,6 +558,7 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
 
     STAMP_DECL
     long long pos = cnt64[C_POS];
+    if (cnt64[C_GEN] < 0) return;                           // generation marked the stream unusable
     // ---- the rings and the per-slot counts come from the blob (zero for a new stream) ------------------------------------
     if (pos == 0) {
         for (int i = tid; i < R * Cw + RV * wpp; i += kThreads) cnt[i] = 0;        // (Sr follows cnt)
@@ -895,14 +955,19 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     make_state_layout(p, W, &a.lay);
     a.state = static_cast<char *>(d_state); a.counters_out = reinterpret_cast<long long *>(d_counters); a.trace = d_trace;
     a.ext_inter = d_ext_inter; a.ext_chan = d_ext_chan; a.ext_npos = ext_npos; a.ext_pos0 = ext_pos0;
-    const int rows = a.nb / kGenThreads;
     const size_t lds_dec = dec_lds_bytes(a.lay);
-    const size_t lds_gen = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb) + (((size_t)a.S / 2 + 8 + 15) & ~(size_t)15);
+    // GENERATE: the fused ranking (stage of S sockets + worklist beside the counters) where a thread draws at most eight
+    // Philox calls per position (S <= 32768) and it all fits a CU; else the counters, the stage over them, fill counters
+    const int kc = ((a.S + 3) / 4 + kGenThreads - 1) / kGenThreads;
+    a.wlcap = std::min(2 * kGenThreads, std::max(64, (a.S / 8 + 63) & ~63));
+    const size_t lds_head = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb / 2);
+    const size_t lds_fused = lds_head + 2u * (size_t)((a.S + 1) & ~1) + 2u * (size_t)a.wlcap;
+    const bool fused = kc <= 8 && lds_fused <= (size_t)scldpc::kMaxLdsBytes;
+    const size_t lds_gen = fused ? lds_fused : lds_head + 4u * (size_t)(a.C / 8 + 4);
     if (const char *v = getenv("SCLDPC_DEBUG_STREAM_WIDE")) a.force_wide = atoi(v);         // diagnostics / tests only
     if (lds_gen > (size_t)scldpc::kMaxLdsBytes)
         return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_stream_run_device: %zu bytes of LDS per stream", lds_gen);
-    void (*gen_kern)(const Args) = rows == 1 ? stream_gen_kernel<1> : rows == 2 ? stream_gen_kernel<2>
-                                   : rows == 4 ? stream_gen_kernel<4> : rows == 8 ? stream_gen_kernel<8> : stream_gen_kernel<16>;
+    void (*gen_kern)(const Args) = fused ? stream_gen_kernel<true> : stream_gen_kernel<false>;
     void (*dec_kern)(const Args) = stream_dec_kernel<4>;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(gen_kern))) return rc_;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(dec_kern))) return rc_;

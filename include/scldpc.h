@@ -331,7 +331,10 @@ int scldpc_r1_moments_device(int32_t ntrials, int32_t ncols, const int32_t *d_r1
  * positions per stream.  Codes and channels are Philox-keyed by (seed, stream0 + stream index, position).
  * d_counters int64 [nstreams][10]: num_erasures, num_blocks_err, num_erasures_exp, num_blocks_err_exp,
  * num_bits_generated, num_blocks_generated, num_bits_generated_exp, num_blocks_generated_exp (the arguments of
- * results_circular, BPF:522-562), positions decoded, positions generated.  d_trace (optional) int32
+ * results_circular, BPF:522-562), positions decoded, positions generated.  "positions generated" < 0 marks a stream
+ * as unusable: its permutation ranking met 256 of a position's Philox keys in one of its >= 1024 buckets (nothing a real
+ * draw does), and rather than rank wrongly both kernels leave such a stream untouched from then on — callers check the
+ * column when they read the counters (bp_decoding.run_streaming does).  d_trace (optional) int32
  * [nstreams][npos][10]: position, value returned by decodeBP_SW_circular, then the eight counters after it.
  * Requires W + dv - 1 <= L/2 (the stream is generated L/2 positions ahead of the decoder, BPF:2001). */
 int64_t scldpc_stream_state_bytes(const scldpc_code_params *p, int32_t W);

@@ -86,7 +86,7 @@ class FakeStreams:
         self.ids = np.arange(stream0, stream0 + nstreams, dtype=np.int64)
         self.done = 0
         self.vns = p.vns_pos
-        self.cnt = np.zeros((nstreams, 8), dtype=np.int64)
+        self.cnt = np.zeros((nstreams, 10), dtype=np.int64)      # eight counters, positions decoded, positions generated
 
     def run(self, npos):
         for k in range(self.done, self.done + npos):
@@ -94,8 +94,8 @@ class FakeStreams:
             bad = (h >> 5) % 11 == 0
             ne = np.where(bad, 1 + h % 37, 0)
             ee = np.where(bad & (ne > 2), ne, 0)
-            self.cnt += np.stack([ne, bad.astype(np.int64), ee, (ee > 0).astype(np.int64),
-                                  np.full_like(ne, self.vns), np.ones_like(ne), np.full_like(ne, self.vns),
-                                  np.ones_like(ne)], axis=1)
+            self.cnt[:, :8] += np.stack([ne, bad.astype(np.int64), ee, (ee > 0).astype(np.int64),
+                                         np.full_like(ne, self.vns), np.ones_like(ne), np.full_like(ne, self.vns),
+                                         np.ones_like(ne)], axis=1)
         self.done += npos
         return torch.from_numpy(self.cnt.copy()), None
