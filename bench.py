@@ -508,30 +508,45 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
     EPS = 0.47 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
     B = a.batch or 8192
-    d_adj = torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev)
-    d_ch = torch.empty((B, p.nw), dtype=torch.int32, device=dev)
-    d_cnt = torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev)
     gen2 = not a.gen1
     if gen2 and not E.sock16_supported(p):
         raise SystemExit("bench.py: the second-generation sampler does not take this ensemble")
-    d_cs = torch.empty((B, p.nk, p.dc), dtype=torch.int16, device=dev) if gen2 else None
+    # two sets of buffers, two streams: the sampler of step k+1 beside the decoder of step k (as C2)
+    nbuf = 1 if a.no_overlap else 2
+    d_adj = [torch.empty((B, p.n, p.dv), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+    d_ch = [torch.empty((B, p.nw), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_cnt = [torch.empty((B, E.NCOUNTERS), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_cs = [torch.empty((B, p.nk, p.dc), dtype=torch.int16, device=dev) if gen2 else None for _ in range(nbuf)]
     run = E.new_run(dev)
-    ev = _events(a.steps, 3)
+    s_dec = torch.cuda.current_stream(dev)
+    s_samp = s_dec if nbuf == 1 else torch.cuda.Stream(dev)
+    sampled = [torch.cuda.Event() for _ in range(nbuf)]
+    decoded = [torch.cuda.Event() for _ in range(nbuf)]
+    ev = _events(a.steps, 4)
 
     def step(k, e=None):
         trial0 = (k * world + rank) * B
-        if e:
-            e[0].record()
-        if gen2:                                        # the sampler emits the CN -> socket table with the code
-            E.sample_philox_sock16(p, SEED, trial0, B, EPS, out=(d_adj, d_cs, d_ch))
-        else:                                           # first generation: sampler.hip, then a cn_sockets pass inside sw_bp
-            E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj, d_ch))
-        if e:
-            e[1].record()
-        E.sw_bp(p, d_adj, d_ch, W, IT, 0, counters=d_cnt, d_cn_sock=d_cs)
-        if e:
-            e[2].record()
-        E.accumulate_run(d_cnt, run, 0)
+        b = k % nbuf
+        with torch.cuda.stream(s_samp):
+            s_samp.wait_event(decoded[b])
+            if e:
+                e[0].record(s_samp)
+            if gen2:                                    # the sampler emits the CN -> socket table with the code
+                E.sample_philox_sock16(p, SEED, trial0, B, EPS, out=(d_adj[b], d_cs[b], d_ch[b]))
+            else:                                       # first generation: sampler.hip, then a cn_sockets pass inside sw_bp
+                E.sample_philox(p, SEED, trial0, B, EPS, out=(d_adj[b], d_ch[b]))
+            if e:
+                e[1].record(s_samp)
+            sampled[b].record(s_samp)
+        with torch.cuda.stream(s_dec):
+            s_dec.wait_event(sampled[b])
+            if e:
+                e[2].record(s_dec)
+            E.sw_bp(p, d_adj[b], d_ch[b], W, IT, 0, counters=d_cnt[b], d_cn_sock=d_cs[b])
+            if e:
+                e[3].record(s_dec)
+            E.accumulate_run(d_cnt[b], run, 0)
+            decoded[b].record(s_dec)
 
     for k in range(a.warmup):
         step(k)
@@ -551,7 +566,7 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
     if rank != 0:
         return
     ms_s = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
-    ms_w = sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps
+    ms_w = sum(e[2].elapsed_time(e[3]) for e in ev) / a.steps
     e_w = W * N_POS * DV                                # edges of a full window (the last W-1 windows are shorter)
     lit = 8.0 * e_w * r["iterations"] / world / a.steps / (ms_w * 1e-3) / 1e9
     b_alg = 16 * p.n * p.dv + p.n // 8
@@ -565,7 +580,8 @@ def run_c4(a, E, dev, rank, world, dist, fence, finish):
            "config": {"workload": f"({DV},{DC}) SC-LDPC L={L_CHAIN} N={N_POS} eps={EPS} decodeBP_SW W={W} I_max={IT} I_init={IT}",
                       "trials_per_gpu_per_step": B, "step": ("device sample (code + CN->socket table) -> decodeBP_SW (window state in LDS) -> plr_computation" if gen2 else
                                "device sample -> CN->socket table -> decodeBP_SW (window state in LDS) -> plr_computation"),
-                      "parallelism": f"trial-sharded x{world} (the eps grid shards by point in bp_decoding.py)"},
+                      "parallelism": f"trial-sharded x{world} (the eps grid shards by point in bp_decoding.py)",
+                      "streams": "sampler(k+1) || decoder(k), double-buffered" if nbuf == 2 else "single stream"},
            "roofline": {"bound": "hbm", "kernel": "sw_ring_kernel" if gen2 else "sw_ring_kernel (+ cn_sockets_kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("sw_ring_kernel", B, "C4")),
                         "alg_bytes_per_trial": share, "ms_per_launch": ms_w,

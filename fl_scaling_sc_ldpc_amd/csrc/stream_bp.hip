@@ -471,21 +471,32 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         const bool doped = position_is_doped(a, g);
         uint32_t c_lo = a.seed_lo, c_hi = a.seed_hi;
         asm volatile("" : "+s"(c_lo), "+s"(c_hi));
-        for (int w = tid; w < wpp; w += kThreads) {                              // channel (BPF:1621-1654)
-            uint32_t word = 0;
-            if (a.ext_chan) {
-                word = a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)(g - a.ext_pos0)) * wpp + w];     // doped positions: all zero
-            } else if (!doped) {
-#pragma unroll
-                for (int c8 = 0; c8 < 8; c8++) {
+        // channel (BPF:1621-1654): Philox call w * 8 + c8 gives bits 4 c8 .. 4 c8 + 3 of word w — one call per lane, the eight
+        // nibbles of a word meet through three lane exchanges (a word's calls are eight consecutive lanes of one wave)
+        if (a.ext_chan || doped) {
+            for (int w = tid; w < wpp; w += kThreads)
+                Sb[slot * wpp + w] = a.ext_chan ? a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)(g - a.ext_pos0)) * wpp + w] : 0u;   // doped: all known
+        } else {
+            const int n8 = wpp * 8;
+            for (int it0 = tid - lane; it0 < n8; it0 += kThreads) {             // wave-uniform trip count
+                const int it = it0 + lane;
+                uint32_t v = 0;
+                if (it < n8) {
                     uint32_t r[4];
-                    philox4x32_10((uint32_t)(w * 8 + c8), 0x80000000u | (uint32_t)g, s_lo, s_hi, c_lo, c_hi, r);
+                    philox4x32_10((uint32_t)it, 0x80000000u | (uint32_t)g, s_lo, s_hi, c_lo, c_hi, r);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) word |= (uint32_t)((r[u] >> 1) < a.thresh) << (c8 * 4 + u);
+                    for (int u = 0; u < 4; u++) v |= (uint32_t)((r[u] >> 1) < a.thresh) << u;
+                    v <<= (it & 7) * 4;
                 }
-                if (w * 32 + 32 > V) word &= (1u << (V - w * 32)) - 1u;
+                v |= (uint32_t)__shfl_xor((int)v, 1, 64);
+                v |= (uint32_t)__shfl_xor((int)v, 2, 64);
+                v |= (uint32_t)__shfl_xor((int)v, 4, 64);
+                if (it < n8 && (it & 7) == 0) {
+                    const int w = it >> 3;
+                    if (w * 32 + 32 > V) v &= (1u << (V - w * 32)) - 1u;
+                    Sb[slot * wpp + w] = v;
+                }
             }
-            Sb[slot * wpp + w] = word;
         }
         STAMP(5);
         for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
