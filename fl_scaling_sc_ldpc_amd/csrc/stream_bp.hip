@@ -45,7 +45,6 @@ using namespace scldpc_dev;
 
 constexpr int kGenThreads = 1024, kDecThreads = 256, kMaxDoped = 32, kMaxL = 256;
 constexpr int kQCap = 512;                          // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
-constexpr int kSwitch = 128;                         // frontier width below which the decode waves stop meeting at barriers (<= 64 entries per wave)
 constexpr int kFrozen = 8;                          // slots of the frozen-position rings in the blob (> 2dv - 1 - (dv - 1) positions)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_BAD = 11, S_NSCAL = 16 };
@@ -768,36 +767,6 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
                         }
                     }
                 }
-            } else if (ncur <= kSwitch) {
-                // a narrow frontier: the window runs to its FIXPOINT and nothing else of it is observable (BPF:1454-1478), so the
-                // waves need no barrier per level — wave w takes entries w, w + 4, … into its own part of qn and follows what its
-                // releases promote, level after level, to exhaustion.  Safe as in full_bp_small.hip: a release claims its VN's S
-                // bit before it decrements the VN's CNs, so a CN whose count reached one shows at most one neighbour still set.
-                constexpr int kWaves = kThreads / 64, wcap = kQCap / kWaves, half_cap = wcap / 2;
-                const int wave = tid >> 6;
-                uint32_t *mine = qn + wave * wcap;
-                int cntw = (ncur - wave + kWaves - 1) / kWaves, cur = 0;
-                if (cntw < 0) cntw = 0;
-                if (lane < cntw) mine[lane] = qc[wave + lane * kWaves];
-                bool lost = false;
-                while (cntw > 0) {
-                    uint32_t *src = mine + cur * half_cap, *dst = mine + (cur ^ 1) * half_cap;
-                    int ncnt = 0;
-                    for (int b0 = 0; b0 < cntw; b0 += 64) {
-                        uint32_t out[4] = {0, 0, 0, 0};
-                        if (b0 + lane < cntw) release((int)(src[b0 + lane] >> 16) - 2 * DV, (int)(src[b0 + lane] & 0xFFFFu), out);
-                        const int mine_n = (out[0] != 0u) + (out[1] != 0u) + (out[2] != 0u) + (out[3] != 0u);
-                        const int incl = (int)wave_inclusive_scan((uint32_t)mine_n);
-                        int idx = ncnt + incl - mine_n;
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (out[i]) { if (idx < half_cap) dst[idx] = out[i] - 1u; else lost = true; idx++; }
-                        ncnt += __builtin_amdgcn_readlane(incl, 63);
-                    }
-                    cntw = min(ncnt, half_cap);
-                    cur ^= 1;
-                }
-                if (lost) *push_ovf = 1;                                          // a private queue overflowed: the next round scans the window
             } else {
                 for (int k0 = (tid >> 6) * 64; k0 < ncur; k0 += kThreads) {
                     uint32_t out[4] = {0, 0, 0, 0};
