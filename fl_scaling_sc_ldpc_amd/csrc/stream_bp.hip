@@ -82,6 +82,15 @@ struct Args {
 
 using scldpc_dev::philox4x32_10;
 
+// a value every lane holds alike (loaded by a vector load), moved to scalar registers: what is derived from it — buffer
+// slots, row pointers, loop bounds — then costs scalar arithmetic and no vector registers
+__device__ __forceinline__ long long uniform64(long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos)     // BPF:1589-1612
 {
     if (a.ndoped == 0) return false;
@@ -92,9 +101,10 @@ __device__ __forceinline__ bool position_is_doped(const Args &a, long long pos) 
 }
 
 // =================================================== GENERATE ============================================================
-// LDS: [scan scratch | scalars | hist: a.nb / 2 words | aux].  FUSED (at most 8 Philox calls per thread, everything within a
-// CU's LDS): aux = the CN-row stage (S sockets, 2 bytes each) + the straddlers' worklist; otherwise aux = the fill counters of
-// cn_rows and the stage lies over hist.  75-80 KB at N = 5000: two workgroups per CU (64 VGPRs, 72 SGPRs).
+// LDS, FUSED (at most 8 Philox calls per thread, everything within a CU's LDS): [scan scratch | scalars | stage: S sockets of
+// 2 bytes | hist: a.nb / 2 words | the straddlers' worklist]; once the ranks are final, what follows the stage holds the
+// socket -> CN row (S entries of 2 bytes).  Otherwise [scan scratch | scalars | hist | fill counters of cn_rows] and the stage
+// lies over hist.  78 KB at N = 5000: two workgroups per CU (64 VGPRs, 72 SGPRs).
 template <bool FUSED>
 __device__ __forceinline__ void stream_gen_body(const Args &a)
 {
@@ -102,34 +112,40 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     extern __shared__ uint32_t lds[];
     uint32_t *wsum = lds;                                               // scan scratch
     int *scal = reinterpret_cast<int *>(wsum + 32);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(scal + S_NSCAL);      // a.nb / 2 words: four nibble-wide (fused) or two 16-bit (wide) bucket counters each
-    uint32_t *aux = hist + a.nb / 2;
+    uint32_t *base = reinterpret_cast<uint32_t *>(scal + S_NSCAL);
+    // a.nb / 2 words: four nibble-wide (fused) or two 16-bit (wide) bucket counters each
+    uint32_t *hist = FUSED ? base + ((a.S + 1) & ~1) / 2 : base;
+    uint32_t *aux = FUSED ? base : hist + a.nb / 2;                     // FUSED: the stage; else the fill counters
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, C = a.C, V = a.V, S = a.S, dv = a.dv, wpp = a.lay.wpp;
     char *st = a.state + (size_t)blockIdx.x * a.lay.total;
-    uint16_t *adj = reinterpret_cast<uint16_t *>(st + a.lay.adj);          // [L][V][dv] position-local CN ids
-    uint16_t *cnsock = reinterpret_cast<uint16_t *>(st + a.lay.cnsock);    // [L][C][dc] sockets of every CN
-    uint16_t *inter = reinterpret_cast<uint16_t *>(st + a.lay.inter);      // [dv][S] CN-local id of socket, by CN position % dv
-    uint32_t *Sb = reinterpret_cast<uint32_t *>(st + a.lay.sbits);         // [L][wpp] channel bits of generated positions
-    uint2 *gkey = reinterpret_cast<uint2 *>(st + a.lay.gkey);             // [S] (key, socket) of straddling buckets' keys, by rank slot
-    uint2 *wlist = reinterpret_cast<uint2 *>(st + a.lay.wlist);           // [S] the same keys as a dense list: (key, socket | first rank << 16)
-    long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
+    // the blob's arrays, addressed from `st` where they are used: kept as seven pointers they would sit in scalar registers the
+    // kernel does not have (72 per wave for two workgroups per CU) and end up in scratch memory
+    auto blob = [&](size_t off) { char *p = st; asm volatile("" : "+s"(p)); return p + off; };
+    auto adj_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.adj)); };          // [L][V][dv] position-local CN ids
+    auto cnsock_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.cnsock)); };    // [L][C][dc] sockets of every CN
+    auto inter_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.inter)); };      // [dv][S] CN-local id of socket, by CN position % dv
+    auto Sb_p = [&] { return reinterpret_cast<uint32_t *>(blob(a.lay.sbits)); };         // [L][wpp] channel bits of generated positions
+    auto gkey_p = [&] { return reinterpret_cast<uint2 *>(blob(a.lay.gkey)); };           // [S] (key, socket) of straddling buckets' keys, by rank slot (rank_wide)
+    auto wlist_p = [&] { return reinterpret_cast<uint2 *>(blob(a.lay.wlist)); };         // [S] the same keys as a dense list: (key, socket | first rank << 16)
+    auto cnt64_p = [&] { return reinterpret_cast<long long *>(blob(a.lay.counters)); };
     const unsigned long long sid = a.sid0 + blockIdx.x;
     const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
 
     STAMP_DECL
     if (tid < S_NSCAL) scal[tid] = 0;
     __syncthreads();
-    const long long pos = cnt64[C_POS];
-    long long gen = cnt64[C_GEN];
+    const long long pos = uniform64(cnt64_p()[C_POS]);
+    long long gen = uniform64(cnt64_p()[C_GEN]);
     if (gen < 0) return;                                    // a stream marked unusable (see rank_wide) stays so
 
     // ---- socket permutation of CN position cpos → inter[cpos % dv] (fill_interleaver_pos, BPF:1763-1787) ----
     // Ranking with 16-bit bucket counters (a.nb buckets, two per word, arrival slots as bytes in the blob): the fallback of
     // rank_nib below for a position in which sixteen keys meet in one of its fine buckets — never on real draws.
     auto rank_wide = [&](long long cpos) {
-        uint8_t *tsl = reinterpret_cast<uint8_t *>(st + a.lay.tslg);
+        uint8_t *tsl = reinterpret_cast<uint8_t *>(blob(a.lay.tslg));
+        uint2 *gkey = gkey_p(), *wlist = wlist_p();
         // Keys are never stored: Philox is pure VALU, so the three passes (count, classify, rank the straddlers) draw them
         // again; what a pass hands to the next lives in LDS (16-bit prefix per bucket, one byte of arrival slot per socket)
         // except the straddling buckets' keys, which are grouped in the stream's blob (3-15 % of the sockets).
@@ -199,7 +215,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                                                     : g0 / (uint32_t)a.dc != (g1 - 1u) / (uint32_t)a.dc);
         };
         auto cn_of = [&](uint32_t rank) { return (uint16_t)(a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc); };
-        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+        uint16_t *dst = inter_p() + (size_t)(cpos % dv) * S;
         for (int q = tid; q < ncalls; q += kThreads) {
             uint32_t r[4];
             philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
@@ -246,17 +262,19 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     };
 
 
-    // Round 3, FUSED: ranking and CN rows in one pass over LDS.  Four nibble-wide counters per word (2 * a.nb buckets) plus the
-    // word's 16-bit first rank; a key's arrival slot in its bucket stays in a register of the thread that drew it (one nibble
-    // per key).  first rank + arrival slot is a rank slot of the key's own, so the socket goes straight to stage[rank slot] —
-    // the CN -> socket rows, no fill counters — and, where the bucket lies inside one CN, CN = first rank / dc goes to the
-    // socket -> CN row.  Keys of buckets that straddle two CNs (7.6 % at N = 5000) are listed; each is ranked against its bucket
-    // mates, whose keys are drawn again from their sockets (Philox is pure arithmetic), and moved to stage[first rank + rank].
-    // No step goes through global memory.  Returns false (for every thread, nothing usable written) when a bucket met a
-    // sixteenth key or the list overflowed: the caller ranks the position again with rank_wide + cn_rows.
+    // Round 3, FUSED: ranking and both tables of the position in LDS.  Four nibble-wide counters per word (2 * a.nb buckets)
+    // plus the word's 16-bit first rank; a key's arrival slot in its bucket stays in a register of the thread that drew it (one
+    // nibble per key).  first rank + arrival slot is a rank slot of the key's own, so the socket goes straight to
+    // stage[rank slot]; only the keys of buckets that straddle two CNs (7.6 % at N = 5000) must be ordered: they are listed, each
+    // is ranked against its bucket mates — whose keys are drawn again from their sockets (Philox is pure arithmetic) — and moved
+    // to stage[first rank + rank].  The stage then IS the CN -> socket rows (CN = rank / dc), and its inverse, built over the
+    // counters, is the socket -> CN row: both leave for the blob as whole lines, nothing else goes through global memory.
+    // Returns false (for every thread, nothing usable written) when a bucket met a sixteenth key or the list overflowed: the
+    // caller ranks the position again with rank_wide + cn_rows.
     auto rank_fused = [&](long long cpos) -> bool {
         const int ncalls = (S + 3) / 4, nbw = a.nb / 2, bshift = a.shift - 1;
-        uint16_t *stage = reinterpret_cast<uint16_t *>(aux), *wl = stage + ((S + 1) & ~1);
+        uint16_t *stage = reinterpret_cast<uint16_t *>(aux), *wl = reinterpret_cast<uint16_t *>(hist + nbw);
+        uint16_t *irow = reinterpret_cast<uint16_t *>(hist);     // the socket -> CN row, once the counters and the worklist are done with
         uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
         asm volatile("" : "+s"(k_lo), "+s"(k_hi));          // (no Philox round keys hoisted out of the position loop and spilled)
         for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
@@ -325,7 +343,6 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
             g0 = ((x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu)) & 0xFFFFu;
             cnt = (x >> sh) & 0xFu;
         };
-        uint16_t *dst = inter + (size_t)(cpos % dv) * S;
         bool spill = false;
 #pragma unroll 1
         for (int k = 0; k * kThreads < ncalls; k++) {
@@ -337,7 +354,6 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
             if (q < ncalls) {
                 uint32_t r[4];
                 philox4x32_10((uint32_t)q, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
-                uint32_t c4[4] = {0, 0, 0, 0};              // (a straddler's entry is written by the pass below)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int s = q * 4 + u;
@@ -345,14 +361,9 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                     uint32_t g0, cnt;
                     bucket_of(r[u], g0, cnt);
                     stage[g0 + ((slots >> (4 * u)) & 15u)] = (uint16_t)s;
-                    if (!straddles(g0, cnt)) { c4[u] = cn_of(g0); continue; }
+                    if (!straddles(g0, cnt)) continue;
                     const int at = atomicAdd(&scal[S_WL], 1);
                     if (at < a.wlcap) wl[at] = (uint16_t)s; else spill = true;
-                }
-                if (q * 4 + 3 < S && (S & 3) == 0) {
-                    *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
-                } else {
-                    for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
                 }
             }
         }
@@ -389,22 +400,23 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (res[h] == 0xFFFFFFFFu) continue;
-                const uint32_t s = res[h] & 0xFFFFu, rank = res[h] >> 16;
-                stage[rank] = (uint16_t)s;
-                dst[s] = cn_of(rank);
+                stage[res[h] >> 16] = (uint16_t)(res[h] & 0xFFFFu);
             }
         }
         __syncthreads();
+        // the stage is the position's sockets in rank order = the CN -> socket rows; its inverse is the socket -> CN row, built
+        // over the counters (done with) so that both leave for the blob as whole lines
+        for (int r = tid; r < S; r += kThreads) irow[stage[r]] = cn_of((uint32_t)r);
+        __syncthreads();
         STAMP(4);
-        // the CN -> socket rows of the position, whole
         {
-            uint16_t *rows = cnsock + (size_t)(cpos % L) * S;
+            uint16_t *rows = cnsock_p() + (size_t)(cpos % L) * S, *dst = inter_p() + (size_t)(cpos % dv) * S;
             if ((S & 1) == 0) {
-                uint32_t *d32 = reinterpret_cast<uint32_t *>(rows);
-                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage);
-                for (int w = tid; w < S / 2; w += kThreads) d32[w] = s32[w];
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(rows), *i32 = reinterpret_cast<uint32_t *>(dst);
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(stage), *r32 = reinterpret_cast<const uint32_t *>(irow);
+                for (int w = tid; w < S / 2; w += kThreads) { d32[w] = s32[w]; i32[w] = r32[w]; }
             } else {
-                for (int w = tid; w < S; w += kThreads) rows[w] = stage[w];
+                for (int w = tid; w < S; w += kThreads) { rows[w] = stage[w]; dst[w] = irow[w]; }
             }
         }
         __syncthreads();
@@ -415,11 +427,11 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     //      mode): staged in LDS (a nibble-wide fill counter per CN hands out the dc places of a row: which place a socket
     //      gets is immaterial, consumers treat a row as a set) and written out whole, `chunk` CNs at a time -------------------
     auto cn_rows = [&](long long cpos) {
-        const uint16_t *row = inter + (size_t)(cpos % dv) * S;
+        const uint16_t *row = inter_p() + (size_t)(cpos % dv) * S;
         uint16_t *stage = reinterpret_cast<uint16_t *>(FUSED ? aux : hist);
         uint32_t *fill = FUSED ? hist : aux;
         const int chunk = FUSED ? C : std::min(C, (a.nb / a.dc) & ~7);         // CNs per pass: the stage over hist holds a.nb sockets
-        uint16_t *dst = cnsock + (size_t)(cpos % L) * C * a.dc;
+        uint16_t *dst = cnsock_p() + (size_t)(cpos % L) * C * a.dc;
         for (int c0 = 0; c0 < C; c0 += chunk) {
             const int c1 = std::min(C, c0 + chunk);
             for (int w = tid; w < (chunk + 7) / 8; w += kThreads) fill[w] = 0;
@@ -450,7 +462,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         bool rows_done = false;
         if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
             const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
-            uint16_t *dst = inter + (size_t)(cpos % dv) * S;
+            uint16_t *dst = inter_p() + (size_t)(cpos % dv) * S;
             for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
             __syncthreads();
         } else {
@@ -473,9 +485,10 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         asm volatile("" : "+s"(c_lo), "+s"(c_hi));
         // channel (BPF:1621-1654): Philox call w * 8 + c8 gives bits 4 c8 .. 4 c8 + 3 of word w — one call per lane, the eight
         // nibbles of a word meet through three lane exchanges (a word's calls are eight consecutive lanes of one wave)
+        uint32_t *Sb = Sb_p() + slot * wpp;
         if (a.ext_chan || doped) {
             for (int w = tid; w < wpp; w += kThreads)
-                Sb[slot * wpp + w] = a.ext_chan ? a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)(g - a.ext_pos0)) * wpp + w] : 0u;   // doped: all known
+                Sb[w] = a.ext_chan ? a.ext_chan[((size_t)blockIdx.x * a.ext_npos + (size_t)(g - a.ext_pos0)) * wpp + w] : 0u;   // doped: all known
         } else {
             const int n8 = wpp * 8;
             for (int it0 = tid - lane; it0 < n8; it0 += kThreads) {             // wave-uniform trip count
@@ -494,19 +507,21 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                 if (it < n8 && (it & 7) == 0) {
                     const int w = it >> 3;
                     if (w * 32 + 32 > V) v &= (1u << (V - w * 32)) - 1u;
-                    Sb[slot * wpp + w] = v;
+                    Sb[w] = v;
                 }
             }
         }
         STAMP(5);
+        const uint16_t *inter = inter_p();
+        uint16_t *vrows = adj_p() + (size_t)slot * V * dv;
         for (int t = tid; t < V; t += kThreads) {                                // wiring (BPF:1841-1854)
             if (dv == 4) {                                  // four independent loads, one 8-byte row store
                 uint32_t loc[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) loc[i] = inter[(size_t)((g + i) & 3) * S + 4 * t + i];
-                *reinterpret_cast<uint2 *>(adj + ((size_t)slot * V + t) * 4) = make_uint2(loc[0] | (loc[1] << 16), loc[2] | (loc[3] << 16));
+                *reinterpret_cast<uint2 *>(vrows + (size_t)t * 4) = make_uint2(loc[0] | (loc[1] << 16), loc[2] | (loc[3] << 16));
             } else {
-                for (int i = 0; i < dv; i++) adj[((size_t)slot * V + t) * dv + i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
+                for (int i = 0; i < dv; i++) vrows[(size_t)t * dv + i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
             }
         }
         __syncthreads();
@@ -522,13 +537,13 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     __syncthreads();
     if (scal[S_BAD]) gen = -1;
     if (tid == 0) {
-        cnt64[C_GEN] = gen;
+        cnt64_p()[C_GEN] = gen;
         if (a.counters_out) a.counters_out[(size_t)blockIdx.x * 10 + 9] = gen;
     }
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void stream_gen_kernel(const Args a)
+__global__ __launch_bounds__(kGenThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void stream_gen_kernel(const Args a)
 {
     stream_gen_body<FUSED>(a);
 }
@@ -568,8 +583,8 @@ __device__ __forceinline__ void stream_dec_body(const Args &a)
     long long *cnt64 = reinterpret_cast<long long *>(st + a.lay.counters);
 
     STAMP_DECL
-    long long pos = cnt64[C_POS];
-    if (cnt64[C_GEN] < 0) return;                           // generation marked the stream unusable
+    long long pos = uniform64(cnt64[C_POS]);
+    if (uniform64(cnt64[C_GEN]) < 0) return;                           // generation marked the stream unusable
     // ---- the rings and the per-slot counts come from the blob (zero for a new stream) ------------------------------------
     if (pos == 0) {
         for (int i = tid; i < R * Cw + RV * wpp; i += kThreads) cnt[i] = 0;        // (Sr follows cnt)
@@ -972,7 +987,8 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     const int kc = ((a.S + 3) / 4 + kGenThreads - 1) / kGenThreads;
     a.wlcap = std::min(2 * kGenThreads, std::max(64, (a.S / 8 + 63) & ~63));
     const size_t lds_head = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb / 2);
-    const size_t lds_fused = lds_head + 2u * (size_t)((a.S + 1) & ~1) + 2u * (size_t)a.wlcap;
+    const size_t s_even = (size_t)((a.S + 1) & ~1);
+    const size_t lds_fused = 4u * ((size_t)32 + S_NSCAL) + 2u * s_even + std::max(2u * (size_t)a.nb + 2u * (size_t)a.wlcap, 2u * s_even);
     const bool fused = kc <= 8 && lds_fused <= (size_t)scldpc::kMaxLdsBytes;
     const size_t lds_gen = fused ? lds_fused : lds_head + 4u * (size_t)(a.C / 8 + 4);
     if (const char *v = getenv("SCLDPC_DEBUG_STREAM_WIDE")) a.force_wide = atoi(v);         // diagnostics / tests only

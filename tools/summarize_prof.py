@@ -39,6 +39,9 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32768      # bench.py's default batch
     config = sys.argv[3] if len(sys.argv) > 3 else "C2"           # tools/profile.sh TAG [CONFIG]
+    # share of every kernel's dispatches that belong to the warm-up step and are left out of the means (C5: a new stream's first
+    # generation launch draws L/2 + ahead positions instead of a step's share; the PMC passes run --steps 2 --warmup 1: 1/3)
+    skip = float(sys.argv[4]) if len(sys.argv) > 4 else (1.0 / 3.0 if config == "C5" else 0.0)
     if config != "C2":
         tag = f"{tag}_{config}"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
@@ -66,15 +69,18 @@ def main():
                 pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[k] = dict(grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]),
                                vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]))
-    mean = lambda v: sum(v) / len(v) if v else None
-    out = {"tag": tag, "trials_per_launch": batch, "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch, mean over dispatches",
+    def mean(v):
+        v = v[int(round(len(v) * skip)):] if v else v
+        return sum(v) / len(v) if v else None
+    out = {"tag": tag, "trials_per_launch": batch,
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch, mean over dispatches" + (f" (the first {skip:.2f} of them, the warm-up step's, left out)" if skip else ""),
            "kernels": {}}
     traffic = {}
     for k, c in pmc.items():
         fetch, write = mean(c.get("FETCH_SIZE")), mean(c.get("WRITE_SIZE"))
         rdreq, hit, miss = mean(c.get("TCC_EA0_RDREQ_sum")), mean(c.get("TCC_HIT_sum")), mean(c.get("TCC_MISS_sum"))
         e = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "TCC_EA0_RDREQ": rdreq, "TCC_HIT": hit, "TCC_MISS": miss,
-             "dispatches": len(c.get("FETCH_SIZE", [])), **meta[k]}
+             "dispatches": len(c.get("FETCH_SIZE", [])) - int(round(len(c.get("FETCH_SIZE", [])) * skip)), **meta[k]}
         if fetch is not None and write is not None:
             e["hbm_bytes_per_launch_raw"] = (fetch + write) * 1024
             e["hbm_bytes_per_launch_corrected"] = (2 * fetch + write) * 1024      # 128 B per read request (calibrated)
