@@ -60,7 +60,7 @@ struct StateLayout {        // byte offsets inside one stream's blob
 struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
     int gen_ahead;              // GENERATE: until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
-    int force_wide;             // diagnostics / tests: rank every position by the 16-bit-counter fallback
+    int force_wide;             // diagnostics / tests: 1 = rank every position by the 16-bit-counter fallback, 2 = and report its overflow
     int wlcap;                  // GENERATE, fused ranking: entries of the straddlers' worklist in LDS (<= 2 * kGenThreads)
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                 }
             }
         }
-        if (crowded >= 256u) scal[S_BAD] = 1;               // arrival slots are kept in a byte (a bucket holds 1-4 keys on average): the stream is
+        if (crowded >= 256u || a.force_wide == 2) scal[S_BAD] = 1;               // arrival slots are kept in a byte (a bucket holds 1-4 keys on average): the stream is
                                                             // marked unusable (gen < 0) instead of being ranked wrongly — 256 of 2^16 keys in one of >= 1024 buckets
         __syncthreads();
         STAMP(7);
@@ -989,7 +989,8 @@ static int stream_run(const scldpc_code_params *p, int32_t nstreams, uint64_t se
     const size_t lds_head = 4u * ((size_t)32 + S_NSCAL + (size_t)a.nb / 2);
     const size_t s_even = (size_t)((a.S + 1) & ~1);
     const size_t lds_fused = 4u * ((size_t)32 + S_NSCAL) + 2u * s_even + std::max(2u * (size_t)a.nb + 2u * (size_t)a.wlcap, 2u * s_even);
-    const bool fused = kc <= 8 && lds_fused <= (size_t)scldpc::kMaxLdsBytes;
+    bool fused = kc <= 8 && lds_fused <= (size_t)scldpc::kMaxLdsBytes;
+    if (const char *v = getenv("SCLDPC_DEBUG_STREAM_LEGACY")) fused = fused && atoi(v) == 0;     // tests: the other LDS layout
     const size_t lds_gen = fused ? lds_fused : lds_head + 4u * (size_t)(a.C / 8 + 4);
     if (const char *v = getenv("SCLDPC_DEBUG_STREAM_WIDE")) a.force_wide = atoi(v);         // diagnostics / tests only
     if (lds_gen > (size_t)scldpc::kMaxLdsBytes)

@@ -36,12 +36,15 @@ def test_streams_equal_cpu_twin(E, oracle, L, N, eps, W, doped, chunks):
             assert cnt[s, :8].tolist() == [o[f] for f in oracle.Stream.FIELDS[2:]] and cnt[s, 8] == o["pos"] + 1
 
 
+@pytest.mark.parametrize("env", ["SCLDPC_DEBUG_STREAM_WIDE", "SCLDPC_DEBUG_STREAM_LEGACY"])
 @pytest.mark.parametrize("L,N,eps,W,doped", [(30, 100, 0.49, 12, (10, 11, 12)), (50, 1000, 0.485, 20, (10, 11, 12)), (50, 5000, 0.47, 20, ())])
-def test_ranking_fallback_with_16_bit_counters_gives_the_same_stream(E, oracle, monkeypatch, L, N, eps, W, doped):
-    """The generation kernel ranks a CN position's keys with nibble-wide bucket counters; a position in which sixteen keys
-    meet in one bucket (never on real draws) is ranked again with 16-bit counters.  Forced here (SCLDPC_DEBUG_STREAM_WIDE):
-    the stream must still equal its CPU twin position by position."""
-    monkeypatch.setenv("SCLDPC_DEBUG_STREAM_WIDE", "1")
+def test_ranking_fallback_with_16_bit_counters_gives_the_same_stream(E, oracle, monkeypatch, L, N, eps, W, doped, env):
+    """The generation kernel ranks a CN position's keys with nibble-wide bucket counters, the CN rows staged beside them; a
+    position in which sixteen keys meet in one bucket (never on real draws) is ranked again with 16-bit counters and its CN
+    rows built in a pass of their own.  Forced here (SCLDPC_DEBUG_STREAM_WIDE); SCLDPC_DEBUG_STREAM_LEGACY runs the kernel's
+    other LDS layout (the one of ensembles beyond 32 768 sockets per position: no separate stage).  Either way the stream
+    must still equal its CPU twin position by position."""
+    monkeypatch.setenv(env, "1")
     p = E.make_params(4, 8, L, N)
     po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
     st = E.Streams(p, 2, seed=23, eps=eps, W=W, doped=doped, stream0=9)
@@ -53,6 +56,24 @@ def test_ranking_fallback_with_16_bit_counters_gives_the_same_stream(E, oracle, 
         for k in range(npos):
             o = twins[s].step()
             assert tr[s, k].tolist() == [o[f] for f in oracle.Stream.FIELDS], (L, N, s, k)
+
+
+def test_a_stream_whose_ranking_overflowed_is_marked_unusable_not_trapped(E, monkeypatch, tmp_path):
+    """256 keys of a position in one of the fallback ranking's buckets cannot be ranked with its byte-wide arrival slots: no
+    real draw does that, but the kernel must neither trap (a GPU fault resets the node for everyone) nor rank wrongly.
+    Forced here (SCLDPC_DEBUG_STREAM_WIDE=2): the stream's "positions generated" column turns negative, later calls leave its
+    counters alone, and the `sw` driver stops with a message."""
+    import torch
+    from fl_scaling_sc_ldpc_amd import bp_decoding as B
+    monkeypatch.setenv("SCLDPC_DEBUG_STREAM_WIDE", "2")
+    st = E.Streams(E.make_params(4, 8, 20, 10), 3, 5, 0.47, 6, (5, 6))
+    c1 = st.run(8)[0].clone()
+    c2 = st.run(8)[0].clone()
+    torch.cuda.synchronize()
+    assert (c1[:, 9] < 0).all() and torch.equal(c1, c2) and (c1[:, :8] == 0).all()
+    with pytest.raises(SystemExit, match="unusable"):
+        B.streaming(["2", "6", "2", "5", "6", "--L", "20", "--N", "10", "--eps-ini", "0.47", "--num-points", "1",
+                     "--streams", "4", "--chunk", "25", "--seed", "3", "--outdir", str(tmp_path), "--quiet"])
 
 
 def test_streaming_cli_writes_results_circular_rows(E, tmp_path):
