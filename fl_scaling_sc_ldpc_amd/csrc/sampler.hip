@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
 // Ensembles beyond 8192 sockets per position (the notebook's N = 10000 is 40000): the bucket counters (16 bits, two per
 // word: every bucket's first rank after the scan), the sockets' arrival slots (one byte each) stay in LDS — 72 KB at
 // S = 40000, two workgroups per CU — and the keys are drawn again by each of the three passes instead of being stored
-// (Philox is pure VALU).  Only the keys of straddling buckets (stream_bp.hip has the same ranking) and the ring of dv
+// (Philox is pure VALU).  Only the keys of straddling buckets (stream_bp.hip's fallback has the same ranking) and the ring of dv
 // permutations live in a per-trial slice of the caller's workspace (L2-resident): the straddlers are ranked from a dense
 // worklist, one trip to the L2 per lane, not one per key and wave.
 template <int ROWS, bool ADJ16>
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
         __syncthreads();
     };
 
-    // Round 3 (as stream_bp.hip's generation): four nibble-wide counters per word plus the word's 16-bit first rank — twice as
-    // many buckets in the same LDS (nb / 2 words: 32768 buckets at N = 10000), so half as many keys sit in buckets that
+    // Round 3 (stream_bp.hip's generation went one step further: its straddlers never leave the LDS): four nibble-wide
+    // counters per word plus the word's 16-bit first rank — twice as many buckets in the same LDS (nb / 2 words: 32768 buckets at N = 10000), so half as many keys sit in buckets that
     // straddle two CNs (15 % instead of 30 %) and half as many straddler records travel through the workspace; the arrival
     // slots are nibbles (one 16-bit store per Philox call).  Returns false (for every thread) when a bucket met a sixteenth key.
     auto rank_nib = [&](int p) -> bool {

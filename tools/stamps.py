@@ -59,7 +59,7 @@ if "--stream" in sys.argv:                      # BASELINE config 5: where does 
     buf.zero_()
     st.run(16)
     show("stream_gen_kernel + stream_dec_kernel (16 positions; sums over both kernels of a stream)", ["(loop top)", "window frontier", "window rounds", "decision + expurgation",
-                                             "generate: ranking (straddlers + rest)", "generate: channel", "generate: wiring",
-                                             "ranking: draw + count", "ranking: scan", "ranking: classify"])
+                                             "generate: straddlers' ranks + inverse row", "generate: copy-out + channel", "generate: wiring",
+                                             "ranking: draw + count", "ranking: scan", "ranking: classify + stage"])
 it = out["counters"][:, 5].float().mean().item()
 print("mean iterations", it)
