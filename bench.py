@@ -146,7 +146,9 @@ def _traffic_fields(tr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps; 0 = the config's default (C2: 100 = 3 s of GPU time, long enough for an outside observer of the GPU's "
+                         "activity and clocks; C3: 10, C4: 50, C5: 50)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="trials (streams for C5) per GPU per step; 0 = the config's default")
     ap.add_argument("--config", default="C2", choices=("C2", "C3", "C4", "C5"))
@@ -166,6 +168,8 @@ def main():
                     help="C2: first-generation kernels: sampler that ranks every key + fixpoint decoder on 16-bit CN words "
                          "(default: sampler_v2 + the 4-bits-per-CN decoder, which also reads the CN -> VN table)")
     a = ap.parse_args()
+    if a.steps <= 0:
+        a.steps = {"C2": 100, "C3": 10, "C4": 50, "C5": 50}[a.config]
 
     # `python bench.py --gpus N` launched plainly (no launcher, no WORLD_SIZE): start the N ranks ourselves, as fresh child
     # processes, BEFORE anything here touches the GPU (never an exec of this process), relay rank 0's one JSON line and the
