@@ -48,7 +48,6 @@ struct SmArgs {
     int off_U, off_q0, off_q1, off_pos, off_scal, off_fb, total, qcap;      // LDS offsets in 32-bit words; qcap in entries (u16)
     const uint16_t *vn_adj16;                       // [T][n][4]   CN index local to its position
     const uint16_t *cn_adj16;                       // [T][nk][8]  VNs of every CN (0xFFFF: none); SOCK: their sockets dv*t + i instead
-    const uint2 *fat;                               // FAT (A/B): [T][nk][8] entries: the neighbour's whole VN row + its socket
     const uint32_t *chan;
     int32_t *counters;
     uint32_t *erased_out;
@@ -59,7 +58,7 @@ struct SmArgs {
 // table, any chain length) instead of global VN ids (which need n < 65535).
 // TRAJ (with LEVEL): the trajectory rows of the BPT build — per iteration deg_1_iter, the VNs recovered and the position of
 // the first erased VN (BPT:988, 1037-1038, 1051), incl. iteration 0's count of degree-1 CNs whose only VN is known (BPF:973).
-template <int BLOCK, bool LEVEL, bool PERSIST, bool SOCK, bool TRAJ = false, bool FAT = false>
+template <int BLOCK, bool LEVEL, bool PERSIST, bool SOCK, bool TRAJ = false>
 __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_sgpr(96))) void full_bp_small_kernel(const SmArgs a)
 {
     constexpr int kWaves = BLOCK / 64;
@@ -127,40 +126,6 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
     int removed = 0, drops = 0;                                          // drops (LEVEL): counts taken from one to zero
     auto step = [&](int c, uint32_t (&out)[4]) {
         out[0] = out[1] = out[2] = out[3] = 0;
-        if constexpr (FAT) {
-            // one gather: the CN's eight entries [cn0:9 cn1:9 cn2:9 cn3:9 | socket:12 | valid], 64 bytes
-            const uint4 *fr = reinterpret_cast<const uint4 *>(a.fat + ((size_t)trial * nk + c) * 8);
-            const uint4 q4[4] = {fr[0], fr[1], fr[2], fr[3]};
-            const uint32_t lo[8] = {q4[0].x, q4[0].z, q4[1].x, q4[1].z, q4[2].x, q4[2].z, q4[3].x, q4[3].z};
-            const uint32_t hi[8] = {q4[0].y, q4[0].w, q4[1].y, q4[1].w, q4[2].y, q4[2].w, q4[3].y, q4[3].w};
-            const int pc = (int)__umulhi((uint32_t)c, a.magic_c);
-            int j = -1, pj = 0;
-            uint32_t elo = 0, ehi = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t sk = (hi[k] >> 4) & 0xFFFu;
-                const int pk = pc - (int)(sk & 3u), jk = pk * V + (int)(sk >> 2);
-                const bool ok = (hi[k] >> 16) & 1u;
-                const uint32_t w = U[ok ? jk >> 5 : 0];
-                if (ok && ((w >> (jk & 31)) & 1u)) { j = jk; pj = pk; elo = lo[k]; ehi = hi[k]; }
-            }
-            if (j < 0) return;
-            const uint32_t bit = 1u << (j & 31);
-            if (!(atomicAnd(&U[j >> 5], ~bit) & bit)) return;
-            removed++;
-            const int base = pj * C;
-            const int cc[4] = {base + (int)(elo & 0x1FFu), base + C + (int)((elo >> 9) & 0x1FFu),
-                               base + 2 * C + (int)((elo >> 18) & 0x1FFu), base + 3 * C + (int)((elo >> 27) | ((ehi & 0xFu) << 5))};
-            uint32_t o[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) o[i] = atomicSub(&cnt[cc[i] >> 3], 1u << ((cc[i] & 7) * 4));
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t old = (o[i] >> ((cc[i] & 7) * 4)) & 15u;
-                if (old == 2u && cc[i] < cn_lim) out[i] = (uint32_t)cc[i] + 1u;
-            }
-            return;
-        }
         const uint4 s4 = crow[c];
         uint32_t jk[8] = {s4.x & 0xFFFFu, s4.x >> 16, s4.y & 0xFFFFu, s4.y >> 16,
                           s4.z & 0xFFFFu, s4.z >> 16, s4.w & 0xFFFFu, s4.w >> 16};
@@ -684,64 +649,4 @@ extern "C" int scldpc_full_bp_traj_device_sock16(const scldpc_code_params *p, in
     if (!d_rows) return scldpc::set_error(SCLDPC_ERR_BAD_ARG, "scldpc_full_bp_traj_device_sock16: null d_rows");
     return launch_small("scldpc_full_bp_traj_device_sock16", true, true, p, ntrials, d_vn_adj16, d_cn_sock16, d_chan_bits, max_it,
                         is_term, d_counters, d_erased_bits, stream, d_rows, rows_cap);
-}
-
-// ---- A/B only (VERDICT r02 #2a): fat CN rows built by a pass over the sampler's two tables, and the fixpoint decoder on them ----
-namespace {
-__global__ __launch_bounds__(256) void fatten_kernel(const SmArgs a, int ntrials, uint2 *fat)
-{
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;            // one thread per (trial, CN, neighbour)
-    if (e >= (size_t)ntrials * a.nk * 8) return;
-    const size_t tc = e >> 3;
-    const int trial = (int)(tc / (size_t)a.nk), c = (int)(tc - (size_t)trial * a.nk);
-    const uint32_t vn = a.cn_adj16[e];
-    uint2 ent = make_uint2(0u, 0u);
-    if (vn != 0xFFFFu) {
-        const uint2 r = reinterpret_cast<const uint2 *>(a.vn_adj16)[(size_t)trial * a.n + vn];
-        const uint32_t c0 = r.x & 0xFFFFu, c1 = r.x >> 16, c2 = r.y & 0xFFFFu, c3 = r.y >> 16;
-        const int pos = (int)__umulhi(vn, a.magic_v), pc = (int)__umulhi((uint32_t)c, a.magic_c);
-        const uint32_t s = 4u * (vn - (uint32_t)(pos * a.V)) + (uint32_t)(pc - pos);
-        ent.x = c0 | (c1 << 9) | (c2 << 18) | ((c3 & 0x1Fu) << 27);
-        ent.y = (c3 >> 5) | (s << 4) | (1u << 16);
-    }
-    fat[e] = ent;
-}
-}  // namespace
-
-extern "C" int scldpc_ab_fatten_device(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
-                                       const uint16_t *d_cn_adj16, void *d_fat, void *stream)
-{
-    if (!scldpc_full_bp_cn16_supported(p) || p->cns_pos > 512 || p->vns_pos > 1024)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_ab_fatten_device: cns_pos <= 512, vns_pos <= 1024");
-    SmArgs a{};
-    make_args(p, 1, &a, 1);
-    scldpc::magic_of(p->vns_pos, a.n + 32, &a.magic_v);
-    scldpc::magic_of(p->cns_pos, a.nk, &a.magic_c);
-    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16;
-    const size_t total = (size_t)ntrials * a.nk * 8;
-    hipLaunchKernelGGL(fatten_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, ntrials,
-                       static_cast<uint2 *>(d_fat));
-    SCLDPC_HIP_CHECK(hipGetLastError());
-    return SCLDPC_OK;
-}
-
-extern "C" int scldpc_ab_full_bp_fixpoint_device_fat(const scldpc_code_params *p, int32_t ntrials, const uint16_t *d_vn_adj16,
-                                                     const uint16_t *d_cn_adj16, const void *d_fat, const uint32_t *d_chan_bits,
-                                                     int32_t is_term, int32_t *d_counters, uint32_t *d_erased_bits, void *stream)
-{
-    if (!scldpc_full_bp_cn16_supported(p) || p->cns_pos > 512 || p->vns_pos > 1024)
-        return scldpc::set_error(SCLDPC_ERR_TOO_LARGE, "scldpc_ab_full_bp_fixpoint_device_fat: cns_pos <= 512, vns_pos <= 1024");
-    SmArgs a{};
-    int per_cu = kPerCu;
-    while (per_cu > 1 && make_args(p, is_term, &a, per_cu) != 0) per_cu--;
-    scldpc::magic_of(p->vns_pos, a.n + 32, &a.magic_v);
-    scldpc::magic_of(p->cns_pos, a.nk, &a.magic_c);
-    a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.fat = static_cast<const uint2 *>(d_fat); a.chan = d_chan_bits;
-    a.counters = d_counters; a.erased_out = d_erased_bits;
-    a.kswitch = kSwitchWidth; a.ntrials = ntrials;
-    void (*kern)(const SmArgs) = full_bp_small_kernel<kBlockSmall, false, false, false, false, true>;
-    if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
-    hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlockSmall), 4u * (size_t)a.total, static_cast<hipStream_t>(stream), a);
-    SCLDPC_HIP_CHECK(hipGetLastError());
-    return SCLDPC_OK;
 }
