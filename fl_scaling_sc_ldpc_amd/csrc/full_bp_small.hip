@@ -275,6 +275,7 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
             } else {
                 run_queue(ncur);
             }
+            STAMP(4);                                                    // (LEVEL) this wave's releases of the iteration
             removed = wave_sum(removed);
             drops = wave_sum(drops);
             if (lane == 0) {
@@ -282,7 +283,9 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
                 if (drops) atomicAdd(&scal[LV_DROP + g], drops);
             }
             if (overflow) scal[LV_OVF + g] = 1;
+            STAMP(5);                                                    // reductions
             __syncthreads();                                             // end of flooding iteration `iter`
+            STAMP(6);                                                    // waiting for the other waves
             // ---- bookkeeping, identical in every thread (full_bp.hip)
             const int deg1 = nfront + ((TRAJ && iter == 0) ? scal[LV_EXTRA0] : 0);      // deg_1_iter, BPF:969-978
             ne -= scal[LV_REM + g];
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
             ncur = scan ? 0 : scal[LV_PUSH + g];
             iter++;
             if (a.max_it > 0 && iter >= a.max_it) break;                 // BPF:1065
+            STAMP(7);                                                    // bookkeeping
         }
         __syncthreads();
         STAMP(1);

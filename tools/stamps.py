@@ -48,6 +48,9 @@ show("sample_philox_v3_kernel", ["(loop top)", "A: worklist of p-1 + clear", "A:
                                  "barrier wait B", "C: classify", "barrier wait C", "channel"])
 out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
+out4 = E.full_bp_cn16(p, a2, cn2, ch2)
+show("full_bp_small_kernel<LEVEL>", ["channel+build", "tail", "final+expurgation", "-", "this wave's releases (queue, two gathers, atomics, append)",
+                                   "reductions", "barrier wait", "bookkeeping"])
 if "--stream" in sys.argv:                      # BASELINE config 5: where does a decoded position's time go?
     ps = E.make_params(4, 8, 50, 5000)
     NS = 2048
