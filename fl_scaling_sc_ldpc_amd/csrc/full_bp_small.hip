@@ -72,6 +72,7 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto decode_trial = [&](const int trial) {
+    STAMP_DECL
     const int n = a.n, nk = a.nk, cn_lim = a.cn_lim, nw = a.nw, V = a.V, C = a.C, L = a.L, qcap = a.qcap;
     const uint2 *vrow = reinterpret_cast<const uint2 *>(a.vn_adj16) + (size_t)trial * n;
     const uint4 *crow = reinterpret_cast<const uint4 *>(a.cn_adj16) + (size_t)trial * nk;
@@ -117,7 +118,6 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
         }
     }
     __syncthreads();
-    STAMP_DECL
     STAMP(0);                                                            // channel + build
     const int nch = scal[SC_NE];
 
