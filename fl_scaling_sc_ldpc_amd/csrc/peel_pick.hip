@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
     uint32_t mti = a.rng_mode == 0 ? a.mt[(size_t)trial * 625 + 624] : 0u;      // MT index, or Philox draw counter
     const unsigned long long gtrial = a.trial0 + (unsigned long long)trial;
 
+    uint32_t prc[4] = {0u, 0u, 0u, 0u};         // the current Philox call's four words
     auto next_u32 = [&]() -> uint32_t {        // wave-uniform result
         if (a.rng_mode == 0) {
             if (mti >= 624u) {                 // twist, in lockstep batches of 64 == the sequential recurrence
@@ -149,19 +150,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
             return y;
         }
-        uint32_t r[4];
-        philox4x32_10(mti >> 2, 0x90000000u, (uint32_t)gtrial, (uint32_t)(gtrial >> 32), a.seed_lo, a.seed_hi, r);
-        const uint32_t y = r[mti & 3u];
+        // draw d is word d & 3 of Philox call d >> 2: one call serves four draws (a call per draw was a quarter of a pick's
+        // instructions; the chain waits on memory, so it bought 3 %)
+        if ((mti & 3u) == 0u)
+            philox4x32_10(mti >> 2, 0x90000000u, (uint32_t)gtrial, (uint32_t)(gtrial >> 32), a.seed_lo, a.seed_hi, prc);
+        const uint32_t y = (mti & 2u) ? ((mti & 1u) ? prc[3] : prc[2]) : ((mti & 1u) ? prc[1] : prc[0]);
         mti++;
         return y;
     };
 
+    STAMP_DECL
     int s = 0;
     for (; s < a.steps && n1 > 0; s++) {
+        STAMP(0);                                           // loop end: r1 store, counters
         // ---- x = _randbelow(n1) ----------------------------------------------------------------
         const int k = 32 - __clz(n1);
         uint32_t x;
         do { x = next_u32() >> (32 - k); } while (x >= (uint32_t)n1);
+        STAMP(1);                                           // the draw
         // ---- m = x-th set bit of the degree-1 bitmap, ascending: block of 64 words, word, bit ------------
         const uint32_t bc = (uint32_t)blk[lane];
         const uint32_t binc = wave_inclusive_scan(bc);
@@ -194,10 +200,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             m = ((B0 * 64 + lane) * kw + q) * 64 + (__ffsll((long long)w) - 1);
         }
         m = __builtin_amdgcn_readlane(m, W0);
+        STAMP(2);                                           // rank-select incl. the bitmap words' trip
         // ---- remove its single VN from all its CNs (PD:769-777) ------------------------------------
         const int j = (int)(ldw(m) & kSumMask);
+        STAMP(3);                                           // the CN word's trip
         int32_t cc[8];
         load_adj<DV, A16>(adj, dv, j, pos_of(j), a.cns_pos, cc);
+        STAMP(4);                                           // the VN row's trip
         bool plus = false, minus = false;
         if (lane < dv) {
             const int c = cc[lane];
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             }
         }
         n1 += __popcll(__ballot(plus)) - __popcll(__ballot(minus));
+        STAMP(5);                                           // the returning atomics' trip + bitmap updates
         picked++; with_pick++;
         if (lane == 0) {
             if (r1) r1[s + 1] = n1;
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             }
         }
     }
+    STAMP_FLUSH();
     // no degree-1 CN left: the count (0) is copied forward, nothing is drawn (PD:765-767)
     if (r1)
         for (int t = s + 1 + lane; t <= a.steps; t += 64) r1[t] = n1;

@@ -48,6 +48,19 @@ show("sample_philox_v3_kernel", ["(loop top)", "A: worklist of p-1 + clear", "A:
                                  "barrier wait B", "C: classify", "barrier wait C", "channel"])
 out3 = E.full_bp_fixpoint_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel", ["channel+build", "peeling", "final+expurgation"])
+if "--pick" in sys.argv:                        # BASELINE config 3: where does a pick's time go?  (8192 single-wave trials = all wave slots)
+    pp = E.make_params(4, 8, 50, 10000)
+    NT = 8192
+    buf = torch.zeros((NT, 16), dtype=torch.int64, device="cuda")
+    assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
+    da, dc = E.sample_philox(pp, 1, 0, NT, 0.48, adj16=True)
+    buf.zero_()
+    E.peel_pick(pp, da, dc, pp.cns_pos * 50, 290000, seed=1, trial0=0, want_r1=True)
+    show("peel_pick_kernel (290 000 picks per trial)", ["loop end: r1 store", "the draw (Philox once per four)", "rank-select incl. the bitmap words' trip",
+                                                     "the CN word's trip", "the VN row's trip", "returning atomics' trip + bitmap updates"])
+    del da, dc
+    buf = torch.zeros((T, 16), dtype=torch.int64, device="cuda")
+    assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
 out4 = E.full_bp_cn16(p, a2, cn2, ch2)
 show("full_bp_small_kernel<LEVEL>", ["channel+build", "tail", "final+expurgation", "-", "this wave's releases (queue, two gathers, atomics, append)",
                                    "reductions", "barrier wait", "bookkeeping"])
