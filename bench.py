@@ -492,10 +492,10 @@ def run_c3(a, E, dev, rank, world, dist, fence, finish):
                       "trials_per_gpu_per_step": B, "step": "device sample -> peel_pick (r1 rows) -> r1_moments",
                       "parallelism": f"trial-sharded x{world}",
                       "streams": "sampler(k+1) || picks(k), double-buffered" if nbuf == 2 else "single stream"},
-           "roofline": {"bound": "hbm", "kernel": "peel_pick_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("peel_pick_kernel", B, "C3")),
+           "roofline": {"bound": "hbm", "kernel": "peel_pick_multi_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, **_traffic_fields(measured_traffic("peel_pick_multi_kernel", B, "C3")),
                         "alg_bytes_per_trial": b_alg, "moments_bytes_per_batch": 24 * (steps_pd + 1), "ms_per_launch": ms_p,
-                        "note": "a chain of 290 000 dependent picks per trial: latency-bound (SURVEY.md §8d says so); the "
+                        "note": "a chain of 290 000 dependent picks per trial, two trials per wave: latency-bound (SURVEY.md §8d says so); the "
                                 "fraction of the HBM roofline is reported, not expected to be high"},
            "kernels_ms": {"sample_philox_big": ms_s, "peel_pick": ms_p},
            "results": {"mean_r1_at_step_0": float(m[1][0]) / max(1.0, float(m[0][0])), "trials_in_moments": int(m[0][0])}}

@@ -30,6 +30,7 @@ constexpr int kBlock = 64;
 struct Args {
     int dv, vns_pos, cns_pos, n, ncn, total_size, steps, nw, nd1;     // nd1 = 64-bit words of the degree-1 bitmap
     int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
+    int ntrials;                    // (multi-trial kernel: the last wave may hold fewer than TPW trials)
     int bshift;                     // a rank-select block covers 2^bshift CNs (64 * 2^(bshift-12) bitmap words)
     uint32_t magic_v, seed_lo, seed_hi;
     unsigned long long trial0;
@@ -246,6 +247,182 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
     }
 }
 
+
+// ---- several trials per wave ------------------------------------------------------------------------------------------------
+// A pick is a chain of four dependent trips to DRAM (bitmap words, the CN's word, the VN's row, dv returning atomics: the
+// stamps say 4.4 us with every wave slot of the chip holding a trial), so throughput = trials in flight — and a wave's 64 lanes
+// have little to do for one trial.  Here a wave steps TPW trials in lockstep, 64 / TPW lanes each: every instruction works
+// for all of them (the draw, the scans — segmented: a DPP row is 16 lanes — the loads), the trips of TPW chains overlap, and
+// twice or four times as many trials are in flight.  For the layout of BASELINE config 3: CN words and degree-1 bitmap in the
+// workspace, 2-byte rows, dv = 4, Philox draws, at most 262 144 pickable CNs (one bitmap word per lane and block).  The draws,
+// the ascending-order selection and the trajectory are those of peel_pick_kernel, value for value (tests/test_gpu_pd.py).
+template <int TPW>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_SGPRS))) void peel_pick_multi_kernel(const Args a)
+{
+    constexpr int LPT = 64 / TPW, Q = 64 / LPT;                           // lanes per trial; rank-select blocks (and block words) per lane
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x, seg = lane / LPT, sl = lane % LPT, sbase = seg * LPT;
+    const int trial = blockIdx.x * TPW + seg;
+    const bool valid = trial < a.ntrials;
+    int *blk = reinterpret_cast<int *>(lds) + seg * 64;                   // #degree-1 CNs per block of 64 bitmap words
+    const int n = a.n, ts = a.total_size;
+    const size_t tix = valid ? (size_t)trial : 0;                         // (lanes of an absent trial idle on trial 0's addresses, predicated off)
+    uint32_t *cn = a.ws + tix * a.ncn;
+    unsigned long long *d1 = a.ws_d1 + tix * a.nd1;
+    const unsigned long long *rows = reinterpret_cast<const unsigned long long *>(a.vn_adj) + tix * n;     // 4 x uint16 per VN
+    const uint32_t *chan = a.chan + tix * a.nw;
+    auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };
+    auto ldw = [&](int c) { return __hip_atomic_load(&cn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // inclusive scan over the LPT lanes of a segment: DPP row_shr inside rows of 16 lanes, row_bcast:15 joins two rows
+    auto seg_scan = [](uint32_t x) {
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+        if constexpr (LPT == 32) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+        return x;
+    };
+    auto seg_bits = [&](unsigned long long m) { return (uint32_t)((m >> sbase) & ((1ull << LPT) - 1ull)); };
+    auto from = [&](uint32_t v, int l) { return (uint32_t)__shfl((int)v, sbase + l, 64); };      // lane l of the own segment
+
+    // ---- per trial: clear, count the erased VNs into their CNs, the degree-1 bitmap --------------------------------------
+    for (int i = sl; i < 64; i += LPT) blk[i] = 0;
+    int ne = 0, n1 = 0;
+    if (valid) {
+        for (int c = sl; c < a.ncn; c += LPT) cn[c] = 0;
+        for (int w = sl; w < a.nw; w += LPT) {
+            uint32_t x = chan[w];
+            if (w == a.nw - 1 && (n & 31)) x &= (1u << (n & 31)) - 1u;
+            ne += __popc(x);
+        }
+    }
+    __syncthreads();                                                      // (one wave: orders the stores above before the atomics)
+    if (valid) {
+        for (int j = sl; j < n; j += LPT) {
+            if ((chan[j >> 5] >> (j & 31)) & 1u) {
+                const unsigned long long r = rows[j];
+                const int base = pos_of(j) * a.cns_pos;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    atomicAdd(&cn[base + i * a.cns_pos + (int)((r >> (16 * i)) & 0xFFFFull)], kCntOne + (uint32_t)j);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long acc = 0ull;                                    // lane 0 of the segment assembles the bitmap words
+        for (int base = 0; base < ((ts + 63) & ~63); base += LPT) {
+            const int c = base + sl;
+            const bool one = valid && c < ts && (ldw(c) >> kCntShift) == 1u;
+            const uint32_t bits = seg_bits(__ballot(one));
+            n1 += __popc(bits);
+            acc |= (unsigned long long)bits << (base & 63);
+            if (((base + LPT) & 63) == 0) {
+                if (valid && sl == 0) {
+                    if ((base >> 6) < a.nd1) d1[base >> 6] = acc;
+                    if (acc) atomicAdd(&blk[base >> a.bshift], __popcll(acc));
+                }
+                acc = 0ull;
+            }
+        }
+        if (valid && sl == 0) for (int w = ((ts + 63) >> 6); w < a.nd1; w++) d1[w] = 0ull;
+    }
+    ne = (int)from(seg_scan((uint32_t)ne), LPT - 1);
+    __syncthreads();
+
+    int picked = 0;
+    int32_t *r1 = a.r1 ? a.r1 + tix * (a.steps + 1) : nullptr;
+    if (valid && sl == 0 && r1) r1[0] = n1;
+    const unsigned long long gtrial = a.trial0 + (unsigned long long)tix;
+    uint32_t mti = 0, prc[4] = {0u, 0u, 0u, 0u};
+    int s = 0;
+    bool alive = valid && a.steps > 0 && n1 > 0;
+    while (__any(alive)) {
+        // ---- x = _randbelow(n1): draws until one is below n1; a trial that has its x waits for the others of the wave ----
+        const int k = 32 - __clz(n1 | 1);
+        uint32_t x = 0;
+        bool need = alive;
+        while (__any(need)) {
+            if (need) {
+                if ((mti & 3u) == 0u)
+                    philox4x32_10(mti >> 2, 0x90000000u, (uint32_t)gtrial, (uint32_t)(gtrial >> 32), a.seed_lo, a.seed_hi, prc);
+                const uint32_t y = (mti & 2u) ? ((mti & 1u) ? prc[3] : prc[2]) : ((mti & 1u) ? prc[1] : prc[0]);
+                mti++;
+                x = y >> (32 - k);
+                need = x >= (uint32_t)n1;
+            }
+        }
+        // ---- m = x-th set bit of the degree-1 bitmap, ascending: block, word, bit -------------------------------------------
+        uint32_t bc[Q], bt = 0;
+#pragma unroll
+        for (int q = 0; q < Q; q++) { bc[q] = (uint32_t)blk[sl * Q + q]; bt += bc[q]; }
+        const uint32_t binc = seg_scan(bt);
+        const int L0 = __ffs((int)seg_bits(__ballot(alive && binc > x))) - 1;            // (alive: n1 > x, so some lane qualifies)
+        const int L0s = L0 < 0 ? 0 : L0;
+        uint32_t r = x - from(binc - bt, L0s);
+        int B0 = L0s * Q;
+#pragma unroll
+        for (int q = 0; q < Q - 1; q++) {
+            const uint32_t cq = from(bc[q], L0s);
+            if (B0 == L0s * Q + q && r >= cq) { r -= cq; B0++; }
+        }
+        unsigned long long word[Q];
+        uint32_t wc = 0;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int widx = B0 * 64 + sl * Q + q;
+            word[q] = (alive && widx < a.nd1) ? __hip_atomic_load(&d1[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            wc += (uint32_t)__popcll(word[q]);
+        }
+        const uint32_t winc = seg_scan(wc);
+        const int W0 = __ffs((int)seg_bits(__ballot(alive && winc > r))) - 1;
+        const int W0s = W0 < 0 ? 0 : W0;
+        r -= from(winc - wc, W0s);
+        int m = 0;
+        if (sl == W0s) {
+            int q = 0;
+            unsigned long long w = word[0];
+#pragma unroll
+            for (int qq = 1; qq < Q; qq++)
+                if (q == qq - 1 && r >= (uint32_t)__popcll(w)) { r -= (uint32_t)__popcll(w); w = word[qq]; q = qq; }
+            for (int g = 0; g < 63 && r; g++, r--) w &= w - 1;
+            m = (B0 * 64 + sl * Q + q) * 64 + (__ffsll((long long)w) - 1);
+        }
+        m = (int)from((uint32_t)m, W0s);
+        if (!alive || (unsigned)m >= (unsigned)ts) m = 0;                  // (m < ts whenever the counts and the bitmap agree)
+        // ---- remove its single VN from its four CNs (PD:769-777) ---------------------------------------------------------------
+        const int j = (int)(ldw(m) & kSumMask);
+        const unsigned long long row = rows[alive ? j : 0];
+        bool plus = false, minus = false;
+        if (alive && sl < 4) {
+            const int c = (pos_of(j) + sl) * a.cns_pos + (int)((row >> (16 * sl)) & 0xFFFFull);
+            const uint32_t nc = (atomicSub(&cn[c], kCntOne + (uint32_t)j) >> kCntShift) - 1u;
+            if (c < ts) {
+                minus = nc == 0u;                                         // was 1
+                plus = nc == 1u;                                          // became 1
+                if (plus || minus) {
+                    atomicXor(&d1[c >> 6], 1ull << (c & 63));
+                    atomicAdd(&blk[c >> a.bshift], plus ? 1 : -1);
+                }
+            }
+        }
+        n1 += __popc(seg_bits(__ballot(plus))) - __popc(seg_bits(__ballot(minus)));
+        if (alive) {
+            picked++;
+            s++;
+            if (sl == 0 && r1) r1[s] = n1;
+        }
+        alive = alive && s < a.steps && n1 > 0;
+    }
+    // no degree-1 CN left: the count (0) is copied forward, nothing is drawn (PD:765-767)
+    if (valid && r1)
+        for (int t = s + 1 + sl; t <= a.steps; t += LPT) r1[t] = n1;
+    if (valid && sl == 0) {
+        int32_t *o = a.out + tix * 4;
+        o[0] = ne; o[1] = picked; o[2] = n1; o[3] = picked;
+    }
+}
+
 }  // namespace
 
 static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const void *d_vn_adj, bool adj16,
@@ -314,6 +491,16 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
                                : (adj16 ? peel_pick_kernel<0, true, G, D> : peel_pick_kernel<0, false, G, D>))
     kern = d1g ? PICK(true, true) : gws ? PICK(true, false) : PICK(false, false);
 #undef PICK
+    // BASELINE config 3's layout: several trials per wave (the chain waits on DRAM: more chains in flight)
+    int tpw = (d1g && adj16 && p->dv == 4 && a.rng_mode == 1 && !d_moments && a.bshift == 12) ? 2 : 1;
+    if (const char *v = getenv("SCLDPC_DEBUG_PICK_TPW")) tpw = tpw > 1 ? atoi(v) : 1;                 // A/B, tests: 1, 2 or 4
+    if (tpw == 2 || tpw == 4) {
+        a.ntrials = ntrials;
+        kern = tpw == 2 ? peel_pick_multi_kernel<2> : peel_pick_multi_kernel<4>;
+        hipLaunchKernelGGL(kern, dim3((ntrials + tpw - 1) / tpw), dim3(kBlock), (size_t)tpw * 64 * 4, static_cast<hipStream_t>(stream), a);
+        SCLDPC_HIP_CHECK(hipGetLastError());
+        return SCLDPC_OK;
+    }
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);
     SCLDPC_HIP_CHECK(hipGetLastError());

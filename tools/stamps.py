@@ -54,6 +54,7 @@ if "--pick" in sys.argv:                        # BASELINE config 3: where does 
     buf = torch.zeros((NT, 16), dtype=torch.int64, device="cuda")
     assert L.scldpc_debug_set_stamps(buf.data_ptr()) == 0
     da, dc = E.sample_philox(pp, 1, 0, NT, 0.48, adj16=True)
+    os.environ["SCLDPC_DEBUG_PICK_TPW"] = "1"   # the stamps sit in the one-trial-per-wave kernel
     buf.zero_()
     E.peel_pick(pp, da, dc, pp.cns_pos * 50, 290000, seed=1, trial0=0, want_r1=True)
     show("peel_pick_kernel (290 000 picks per trial)", ["loop end: r1 store", "the draw (Philox once per four)", "rank-select incl. the bitmap words' trip",
