@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
 // stamps say 4.4 us with every wave slot of the chip holding a trial), so throughput = trials in flight — and a wave's 64 lanes
 // have little to do for one trial.  Here a wave steps TPW trials in lockstep, 64 / TPW lanes each: every instruction works
 // for all of them (the draw, the scans — segmented: a DPP row is 16 lanes — the loads), the trips of TPW chains overlap, and
-// twice or four times as many trials are in flight.  For the layout of BASELINE config 3: CN words and degree-1 bitmap in the
+// twice or four times as many trials are in flight.  The rank-select has three levels (64 blocks, 8 sub-blocks, 8 words; the
+// counts of the first two in LDS, 1.25 KB per trial so that 32 waves still share a CU): a pick reads 64 bytes of the bitmap, not
+// 512.  For the layout of BASELINE config 3: CN words and degree-1 bitmap in the
 // workspace, 2-byte rows, dv = 4, Philox draws, at most 262 144 pickable CNs (one bitmap word per lane and block).  The draws,
 // the ascending-order selection and the trajectory are those of peel_pick_kernel, value for value (tests/test_gpu_pd.py).
 template <int TPW>
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
     const int lane = threadIdx.x, seg = lane / LPT, sl = lane % LPT, sbase = seg * LPT;
     const int trial = blockIdx.x * TPW + seg;
     const bool valid = trial < a.ntrials;
-    int *blk = reinterpret_cast<int *>(lds) + seg * 64;                   // #degree-1 CNs per block of 64 bitmap words
+    int *blk = reinterpret_cast<int *>(lds) + seg * (64 + 256);           // #degree-1 CNs per block of 64 bitmap words
+    uint32_t *sub = reinterpret_cast<uint32_t *>(blk + 64);               // ... and per sub-block of 8 words (64 bytes of the bitmap), 16 bits each
+    auto sub_add = [&](int i, int d) { atomicAdd(&sub[i >> 1], (uint32_t)d << ((i & 1) * 16)); };      // (counts <= 512: no carry, no borrow)
     const int n = a.n, ts = a.total_size;
     const size_t tix = valid ? (size_t)trial : 0;                         // (lanes of an absent trial idle on trial 0's addresses, predicated off)
     uint32_t *cn = a.ws + tix * a.ncn;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
     auto from = [&](uint32_t v, int l) { return (uint32_t)__shfl((int)v, sbase + l, 64); };      // lane l of the own segment
 
     // ---- per trial: clear, count the erased VNs into their CNs, the degree-1 bitmap --------------------------------------
-    for (int i = sl; i < 64; i += LPT) blk[i] = 0;
+    for (int i = sl; i < 64 + 256; i += LPT) blk[i] = 0;
     int ne = 0, n1 = 0;
     if (valid) {
         for (int c = sl; c < a.ncn; c += LPT) cn[c] = 0;
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             if (((base + LPT) & 63) == 0) {
                 if (valid && sl == 0) {
                     if ((base >> 6) < a.nd1) d1[base >> 6] = acc;
-                    if (acc) atomicAdd(&blk[base >> a.bshift], __popcll(acc));
+                    if (acc) { atomicAdd(&blk[base >> a.bshift], __popcll(acc)); sub_add(base >> 9, __popcll(acc)); }
                 }
                 acc = 0ull;
             }
@@ -366,27 +370,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
             const uint32_t cq = from(bc[q], L0s);
             if (B0 == L0s * Q + q && r >= cq) { r -= cq; B0++; }
         }
-        unsigned long long word[Q];
-        uint32_t wc = 0;
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int widx = B0 * 64 + sl * Q + q;
-            word[q] = (alive && widx < a.nd1) ? __hip_atomic_load(&d1[widx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            wc += (uint32_t)__popcll(word[q]);
-        }
+        // the block's eight sub-blocks of eight words, then the sub-block's eight words (64 bytes of the bitmap, one request)
+        const uint32_t sc = sl < 8 ? (sub[(B0 * 8 + sl) >> 1] >> ((sl & 1) * 16)) & 0xFFFFu : 0u;
+        const uint32_t sinc = seg_scan(sc);
+        const int S0 = __ffs((int)seg_bits(__ballot(alive && sinc > r))) - 1;
+        const int S0s = S0 < 0 ? 0 : S0;
+        r -= from(sinc - sc, S0s);
+        const int wbase = (B0 * 8 + S0s) * 8;
+        unsigned long long word = 0ull;
+        if (alive && sl < 8 && wbase + sl < a.nd1) word = __hip_atomic_load(&d1[wbase + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t wc = (uint32_t)__popcll(word);
         const uint32_t winc = seg_scan(wc);
         const int W0 = __ffs((int)seg_bits(__ballot(alive && winc > r))) - 1;
         const int W0s = W0 < 0 ? 0 : W0;
         r -= from(winc - wc, W0s);
         int m = 0;
         if (sl == W0s) {
-            int q = 0;
-            unsigned long long w = word[0];
-#pragma unroll
-            for (int qq = 1; qq < Q; qq++)
-                if (q == qq - 1 && r >= (uint32_t)__popcll(w)) { r -= (uint32_t)__popcll(w); w = word[qq]; q = qq; }
+            unsigned long long w = word;
             for (int g = 0; g < 63 && r; g++, r--) w &= w - 1;
-            m = (B0 * 64 + sl * Q + q) * 64 + (__ffsll((long long)w) - 1);
+            m = (wbase + sl) * 64 + (__ffsll((long long)w) - 1);
         }
         m = (int)from((uint32_t)m, W0s);
         if (!alive || (unsigned)m >= (unsigned)ts) m = 0;                  // (m < ts whenever the counts and the bitmap agree)
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
                 if (plus || minus) {
                     atomicXor(&d1[c >> 6], 1ull << (c & 63));
                     atomicAdd(&blk[c >> a.bshift], plus ? 1 : -1);
+                    sub_add(c >> 9, plus ? 1 : -1);
                 }
             }
         }
@@ -497,7 +500,7 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
     if (tpw == 2 || tpw == 4) {
         a.ntrials = ntrials;
         kern = tpw == 2 ? peel_pick_multi_kernel<2> : peel_pick_multi_kernel<4>;
-        hipLaunchKernelGGL(kern, dim3((ntrials + tpw - 1) / tpw), dim3(kBlock), (size_t)tpw * 64 * 4, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(kern, dim3((ntrials + tpw - 1) / tpw), dim3(kBlock), (size_t)tpw * (64 + 256) * 4, static_cast<hipStream_t>(stream), a);
         SCLDPC_HIP_CHECK(hipGetLastError());
         return SCLDPC_OK;
     }
