@@ -55,12 +55,12 @@ __device__ __forceinline__ uint32_t bits_at(const uint32_t *w, int nw, long long
 }
 
 template <int DV, int DC>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void sw_ring_kernel(const RArgs a)
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void sw_ring_kernel(const RArgs a)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *cnt = lds;                                                  // [R][Cw] words of 8 count nibbles
     uint32_t *S = lds + a.off_S;                                          // [RV][wpp]
-    uint32_t *fbits = lds + a.off_fb;                                     // snapshot of the window's count-one CNs: [W][Cw]
+    uint8_t *fbits = reinterpret_cast<uint8_t *>(lds + a.off_fb);         // snapshot of the window's count-one CNs: [W][Cw] bytes, bit k = CN 8w + k
     uint32_t *q[2] = {lds + a.off_q0, lds + a.off_q1};
     int *pos_cnt = reinterpret_cast<int *>(lds + a.off_pos);
     int *pos_ss = pos_cnt + a.L;
@@ -277,17 +277,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(96))) void s
                 for (int p = posW; p < phi; p++)
                     for (int w = tid; w < Cw; w += kBlock) {
                         const uint32_t y = cnt[cslot(p) + w] ^ 0x11111111u;
-                        fbits[(p - posW) * Cw + w] = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+                        uint32_t z = (~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u) >> 3;      // bit 4k: CN 8w + k
+                        z = (z | (z >> 3)) & 0x03030303u;
+                        z = (z | (z >> 6)) & 0x000F000Fu;
+                        fbits[(p - posW) * Cw + w] = (uint8_t)((z | (z >> 12)) & 0xFFu);
                     }
                 __syncthreads();
                 for (int p = posW; p < phi; p++)
                     for (int w0 = (tid >> 6) * 64; w0 < Cw; w0 += kBlock) {          // wave-uniform trip count (append scans)
                         const int w = w0 + lane;
-                        uint32_t z = w < Cw ? fbits[(p - posW) * Cw + w] : 0u;
+                        uint32_t z = w < Cw ? (uint32_t)fbits[(p - posW) * Cw + w] : 0u;
                         while (__any(z != 0u)) {
                             uint32_t out[4] = {0, 0, 0, 0};
                             if (z) {
-                                const int k = (__ffs((int)z) - 1) >> 2;
+                                const int k = __ffs((int)z) - 1;
                                 z &= z - 1;
                                 if (w * 8 + k < C) release(p, w * 8 + k, out);
                             }
@@ -394,10 +397,12 @@ int ring_args(const scldpc_code_params *p, int W, RArgs *a)
     auto take = [&](int words) { int o = off; off += (words + 3) & ~3; return o; };
     take(a->R * a->Cw);
     a->off_S = take(a->RV * a->wpp);
-    a->off_fb = take(W * a->Cw);
+    a->off_fb = take((W * a->Cw + 3) / 4);
     a->off_pos = take(2 * p->L);
     a->off_scal = take(R_N);
-    int qcap = (scldpc::kMaxLdsBytes / 7 / 4 - 64 - off) / 2;            // aim at seven workgroups per CU
+    int per_cu = 8;                                                     // aim at eight workgroups per CU (all 32 wave slots)
+    if (const char *v = getenv("SCLDPC_DEBUG_RING_PER_CU")) per_cu = atoi(v) == 7 ? 7 : 8;
+    int qcap = (scldpc::kMaxLdsBytes / per_cu / 4 - 64 - off) / 2;
     if (qcap < 512) qcap = 512;
     if (qcap > 4096) qcap = 4096;
     qcap &= ~3;
