@@ -45,6 +45,7 @@ using namespace scldpc_dev;
 
 constexpr int kGenThreads = 1024, kDecThreads = 256, kMaxDoped = 32, kMaxL = 256;
 constexpr int kQCap = 512;                          // frontier-queue entries (an overflow falls back to a scan of the window's CNs)
+constexpr int kScratch = 2048;                       // GENERATE: keys of straddling buckets ordered at a time (beyond: the fallback ranking)
 constexpr int kFrozen = 8;                          // slots of the frozen-position rings in the blob (> 2dv - 1 - (dv - 1) positions)
 enum { C_NE = 0, C_BE, C_EE, C_BEE, C_GB, C_GBL, C_GBE, C_GBLE, C_POS, C_GEN, C_NCOUNT = 16 };
 enum { S_PUSH = 0, S_OVF = 3, S_REM = 6, S_ACC = 9, S_WL = 10, S_BAD = 11, S_NSCAL = 16 };
@@ -273,12 +274,13 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     // caller ranks the position again with rank_wide + cn_rows.
     auto rank_fused = [&](long long cpos) -> bool {
         const int ncalls = (S + 3) / 4, nbw = a.nb / 2, bshift = a.shift - 1;
-        uint16_t *stage = reinterpret_cast<uint16_t *>(aux), *wl = reinterpret_cast<uint16_t *>(hist + nbw);
+        uint16_t *stage = reinterpret_cast<uint16_t *>(aux);
+        uint32_t *bl = hist + nbw;                               // the straddling buckets: first rank | size << 16 (a.wlcap / 2 entries)
         uint16_t *irow = reinterpret_cast<uint16_t *>(hist);     // the socket -> CN row, once the counters and the worklist are done with
         uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
         asm volatile("" : "+s"(k_lo), "+s"(k_hi));          // (no Philox round keys hoisted out of the position loop and spilled)
         for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
-        if (tid == 0) { scal[S_WL] = 0; scal[S_OVF] = 0; }
+        if (tid == 0) { scal[S_WL] = 0; scal[S_OVF] = 0; scal[S_REM] = 0; }
         __syncthreads();
         // the arrival slots (a nibble each) of the keys this thread draws: call tid + k * kThreads in bits 16 (k & 1) of pk[k >> 1];
         // the loops over k are not unrolled (their trip count is uniform: the selects are scalar), or eight inlined Philox
@@ -361,9 +363,9 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                     uint32_t g0, cnt;
                     bucket_of(r[u], g0, cnt);
                     stage[g0 + ((slots >> (4 * u)) & 15u)] = (uint16_t)s;
-                    if (!straddles(g0, cnt)) continue;
-                    const int at = atomicAdd(&scal[S_WL], 1);
-                    if (at < a.wlcap) wl[at] = (uint16_t)s; else spill = true;
+                    if (((slots >> (4 * u)) & 15u) != 0u || !straddles(g0, cnt)) continue;
+                    const int at = atomicAdd(&scal[S_WL], 1);               // the first key to arrive lists its straddling bucket
+                    if (at < a.wlcap / 2) bl[at] = g0 | (cnt << 16); else spill = true;
                 }
             }
         }
@@ -371,39 +373,40 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         __syncthreads();
         STAMP(9);
         if (scal[S_OVF]) { __syncthreads(); return false; }
-        // the straddlers, one per lane, two rounds at most (wlcap <= 2 * kThreads): rank among the bucket mates, then — when
-        // every lane has read its mates — the move to the rank's own slot
+        // the straddling buckets, one per lane: the bucket's keys are drawn again from their sockets — once each — into a
+        // scratch over the counters (done with: the list carries first rank and size), ordered there, and the sockets put back
+        // in rank order.  A lane owns its bucket's slots of the stage: no other lane reads or writes them.
         {
-            const int nwl = scal[S_WL];
-            uint32_t res[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // socket | rank << 16
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int w = tid + h * kThreads;
-                if (w >= nwl) continue;
-                const uint32_t s = wl[w];
-                uint32_t r[4];
-                philox4x32_10(s >> 2, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r);
-                const uint32_t key = (s & 2u) ? ((s & 1u) ? r[3] : r[2]) : ((s & 1u) ? r[1] : r[0]);
-                uint32_t g0, cnt;
-                bucket_of(key, g0, cnt);
-                uint32_t rank = g0;
-                for (uint32_t m = 0; m < cnt; m++) {        // a key's own socket compares false with itself
+            const int nbl = scal[S_WL];
+            const int scap = min(kScratch, ((nbw * 4) / 6) & ~1);              // 6 bytes an entry, inside the counters' words
+            uint32_t *kscr = hist;                                              // [scap] keys
+            uint16_t *sscr = reinterpret_cast<uint16_t *>(hist + scap);         // [scap] their sockets
+            bool over = false;
+            for (int b = tid; b < nbl; b += kThreads) {
+                const uint32_t g0 = bl[b] & 0xFFFFu, cnt = bl[b] >> 16;
+                const int base = atomicAdd(&scal[S_REM], (int)cnt);
+                if (base + (int)cnt > scap) { over = true; continue; }
+                for (uint32_t m = 0; m < cnt; m++) {
                     const uint32_t s2 = stage[g0 + m];
                     uint32_t r2[4];
                     philox4x32_10(s2 >> 2, (uint32_t)cpos, s_lo, s_hi, k_lo, k_hi, r2);
-                    const uint32_t k2 = (s2 & 2u) ? ((s2 & 1u) ? r2[3] : r2[2]) : ((s2 & 1u) ? r2[1] : r2[0]);
-                    rank += (k2 < key) || (k2 == key && s2 < s);
+                    kscr[base + m] = (s2 & 2u) ? ((s2 & 1u) ? r2[3] : r2[2]) : ((s2 & 1u) ? r2[1] : r2[0]);
+                    sscr[base + m] = (uint16_t)s2;
                 }
-                res[h] = s | (rank << 16);
+                for (uint32_t m = 0; m < cnt; m++) {
+                    const uint32_t km = kscr[base + m], sm = sscr[base + m];
+                    uint32_t rank = g0;
+                    for (uint32_t m2 = 0; m2 < cnt; m2++) {                     // (a key compares false with itself)
+                        const uint32_t k2 = kscr[base + m2], s2 = sscr[base + m2];
+                        rank += (k2 < km) || (k2 == km && s2 < sm);
+                    }
+                    stage[rank] = (uint16_t)sm;
+                }
             }
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (res[h] == 0xFFFFFFFFu) continue;
-                stage[res[h] >> 16] = (uint16_t)(res[h] & 0xFFFFu);
-            }
+            if (over) scal[S_OVF] = 1;
         }
         __syncthreads();
+        if (scal[S_OVF]) { __syncthreads(); return false; }
         // the stage is the position's sockets in rank order = the CN -> socket rows; its inverse is the socket -> CN row, built
         // over the counters (done with) so that both leave for the blob as whole lines
         for (int r = tid; r < S; r += kThreads) irow[stage[r]] = cn_of((uint32_t)r);
