@@ -62,7 +62,7 @@ struct Args {
     int dv, dc, L, C, V, S, W, nb, shift, lgchunk, dc_shift, npos;
     int gen_ahead;              // GENERATE: until gen == pos + L/2 + gen_ahead (and the first L/2 positions of a new stream)
     int force_wide;             // diagnostics / tests: 1 = rank every position by the 16-bit-counter fallback, 2 = and report its overflow
-    int wlcap;                  // GENERATE, fused ranking: entries of the straddlers' worklist in LDS (<= 2 * kGenThreads)
+    int wlcap;                  // GENERATE, fused ranking: the list of straddling buckets holds wlcap / 2 entries (<= kGenThreads: one per lane)
     int ndoped, doped[kMaxDoped];
     uint32_t seed_lo, seed_hi, thresh;
     unsigned long long sid0;
@@ -266,9 +266,9 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     // Round 3, FUSED: ranking and both tables of the position in LDS.  Four nibble-wide counters per word (2 * a.nb buckets)
     // plus the word's 16-bit first rank; a key's arrival slot in its bucket stays in a register of the thread that drew it (one
     // nibble per key).  first rank + arrival slot is a rank slot of the key's own, so the socket goes straight to
-    // stage[rank slot]; only the keys of buckets that straddle two CNs (7.6 % at N = 5000) must be ordered: they are listed, each
-    // is ranked against its bucket mates — whose keys are drawn again from their sockets (Philox is pure arithmetic) — and moved
-    // to stage[first rank + rank].  The stage then IS the CN -> socket rows (CN = rank / dc), and its inverse, built over the
+    // stage[rank slot]; only the keys of buckets that straddle two CNs (7.6 % at N = 5000) must be ordered: the buckets are
+    // listed by their first arrivals, and a lane per bucket draws its keys again from their sockets (Philox is pure arithmetic),
+    // orders them and puts the sockets back in rank order.  The stage then IS the CN -> socket rows (CN = rank / dc), and its inverse, built over the
     // counters, is the socket -> CN row: both leave for the blob as whole lines, nothing else goes through global memory.
     // Returns false (for every thread, nothing usable written) when a bucket met a sixteenth key or the list overflowed: the
     // caller ranks the position again with rank_wide + cn_rows.
