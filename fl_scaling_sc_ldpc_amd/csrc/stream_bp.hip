@@ -267,11 +267,11 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     // plus the word's 16-bit first rank; a key's arrival slot in its bucket stays in a register of the thread that drew it (one
     // nibble per key).  first rank + arrival slot is a rank slot of the key's own, so the socket goes straight to
     // stage[rank slot]; only the keys of buckets that straddle two CNs (7.6 % at N = 5000) must be ordered: the buckets are
-    // listed by their first arrivals, and a lane per bucket draws its keys again from their sockets (Philox is pure arithmetic),
-    // orders them and puts the sockets back in rank order.  The stage then IS the CN -> socket rows (CN = rank / dc), and its inverse, built over the
-    // counters, is the socket -> CN row: both leave for the blob as whole lines, nothing else goes through global memory.
-    // Returns false (for every thread, nothing usable written) when a bucket met a sixteenth key or the list overflowed: the
-    // caller ranks the position again with rank_wide + cn_rows.
+    // listed by their first arrivals, and a lane per bucket draws its keys again from their sockets (Philox is pure
+    // arithmetic), orders them and puts the sockets back in rank order.  The stage then IS the CN -> socket rows (CN = rank /
+    // dc), and its inverse, built over the counters, is the socket -> CN row: both leave for the blob as whole lines, nothing
+    // else goes through global memory.  Returns false (for every thread, nothing usable written) when a bucket met a sixteenth
+    // key or a list overflowed: the caller ranks the position again with rank_wide + cn_rows.
     auto rank_fused = [&](long long cpos) -> bool {
         const int ncalls = (S + 3) / 4, nbw = a.nb / 2, bshift = a.shift - 1;
         uint16_t *stage = reinterpret_cast<uint16_t *>(aux);
