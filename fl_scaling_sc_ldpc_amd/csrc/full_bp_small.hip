@@ -276,8 +276,12 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
                 run_queue(ncur);
             }
             STAMP(4);                                                    // (LEVEL) this wave's releases of the iteration
-            removed = wave_sum(removed);
-            drops = wave_sum(drops);
+            {   // one reduction for both counts: a CN is queued once in its life and an iteration's entries are dealt to the four
+                // waves, so a wave releases at most nk / 4 + 64 <= 16 448 VNs per iteration (15 bits) and zeroes at most four
+                // times as many CNs (17 bits)
+                const uint32_t both = (uint32_t)wave_sum((int)((uint32_t)removed | ((uint32_t)drops << 15)));
+                removed = (int)(both & 0x7FFFu); drops = (int)(both >> 15);
+            }
             if (lane == 0) {
                 if (removed) atomicAdd(&scal[LV_REM + g], removed);
                 if (drops) atomicAdd(&scal[LV_DROP + g], drops);
