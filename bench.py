@@ -271,7 +271,7 @@ def run_c2(a, E, dev, rank, world, dist, fence, finish):
     L_CHAIN, N_POS = 50, 1000
     EPS = 0.48 if a.eps is None else a.eps
     p = E.make_params(DV, DC, L_CHAIN, N_POS)
-    B = a.batch or 32768
+    B = a.batch or 65536                                # 36.6 rounds of the 1792 resident decoder workgroups: the tail of long trials weighs less (+1.5 % over 32768)
     TRAJ_ROWS = 640                                     # iterations kept per trial in --traj mode (the longest run at this size: ~520)
     if a.traj:
         a.flooding = True                               # the rows come from the iteration-exact decoder
