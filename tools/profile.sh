@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc WRITE_SIZE  (own pass)       → HBM write bytes per dispatch
 # Raw CSVs land in gpurun_out/prof_$TAG/; tools/summarize_prof.py condenses them into profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-C2}            # bench.py --config; the other configs land in gpurun_out/prof_${TAG}_${CFG}/
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG

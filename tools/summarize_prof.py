@@ -36,8 +36,8 @@ def short(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32768      # bench.py's default batch
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 65536      # bench.py default batch (C2)
     config = sys.argv[3] if len(sys.argv) > 3 else "C2"           # tools/profile.sh TAG [CONFIG]
     # share of every kernel's dispatches that belong to the warm-up step and are left out of the means (C5: a new stream's first
     # generation launch draws L/2 + ahead positions instead of a step's share; the PMC passes run --steps 2 --warmup 1: 1/3)
