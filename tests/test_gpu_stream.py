@@ -36,6 +36,27 @@ def test_streams_equal_cpu_twin(E, oracle, L, N, eps, W, doped, chunks):
             assert cnt[s, :8].tolist() == [o[f] for f in oracle.Stream.FIELDS[2:]] and cnt[s, 8] == o["pos"] + 1
 
 
+@pytest.mark.parametrize("env", ["", "SCLDPC_DEBUG_STREAM_WIDE", "SCLDPC_DEBUG_STREAM_LEGACY"])
+@pytest.mark.parametrize("dc,N,eps,W", [(6, 300, 0.6, 12), (12, 300, 0.3, 10), (10, 250, 0.36, 8)])
+def test_streams_with_other_check_degrees_equal_cpu_twin(E, oracle, monkeypatch, dc, N, eps, W, env):
+    """dc != 8 (no power of two: CN = rank / dc by division; CN rows of 12, 20 or 24 bytes read entry by entry): every
+    generation path and the decoder against the CPU twin, position by position."""
+    if env:
+        monkeypatch.setenv(env, "1")
+    L = 30
+    p = E.make_params(4, dc, L, N)
+    po = oracle.Params(4, dc, L, p.cns_pos, p.vns_pos)
+    st = E.Streams(p, 2, seed=31, eps=eps, W=W, doped=(7, 8, 9), stream0=3)
+    twins = [oracle.Stream(po, 31, eps, W, (7, 8, 9), rng_mode=1, decoder=1, sid=3 + s) for s in range(2)]
+    for npos in (45, 40):
+        cnt, tr = st.run(npos, trace=True)
+        tr = tr.cpu().numpy()
+        for s in range(2):
+            for k in range(npos):
+                o = twins[s].step()
+                assert tr[s, k].tolist() == [o[f] for f in oracle.Stream.FIELDS], (dc, s, k)
+
+
 @pytest.mark.parametrize("env", ["SCLDPC_DEBUG_STREAM_WIDE", "SCLDPC_DEBUG_STREAM_LEGACY"])
 @pytest.mark.parametrize("L,N,eps,W,doped", [(30, 100, 0.49, 12, (10, 11, 12)), (50, 1000, 0.485, 20, (10, 11, 12)), (50, 5000, 0.47, 20, ())])
 def test_ranking_fallback_with_16_bit_counters_gives_the_same_stream(E, oracle, monkeypatch, L, N, eps, W, doped, env):
