@@ -126,11 +126,15 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
     auto blob = [&](size_t off) { char *p = st; asm volatile("" : "+s"(p)); return p + off; };
     auto adj_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.adj)); };          // [L][V][dv] position-local CN ids
     auto cnsock_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.cnsock)); };    // [L][C][dc] sockets of every CN
-    auto inter_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.inter)); };      // [dv][S] CN-local id of socket, by CN position % dv
+    auto inter_p = [&] { return reinterpret_cast<uint16_t *>(blob(a.lay.inter)); };      // [dv][S] CN-local id of socket (at tp(socket): by edge, then VN), by CN position % dv
     auto Sb_p = [&] { return reinterpret_cast<uint32_t *>(blob(a.lay.sbits)); };         // [L][wpp] channel bits of generated positions
     auto gkey_p = [&] { return reinterpret_cast<uint2 *>(blob(a.lay.gkey)); };           // [S] (key, socket) of straddling buckets' keys, by rank slot (rank_wide)
     auto wlist_p = [&] { return reinterpret_cast<uint2 *>(blob(a.lay.wlist)); };         // [S] the same keys as a dense list: (key, socket | first rank << 16)
     auto cnt64_p = [&] { return reinterpret_cast<long long *>(blob(a.lay.counters)); };
+    // a socket -> CN row is kept by edge: entry of socket s = dv*t + i at i * V + t, so that the wiring of a VN position reads
+    // V consecutive entries of each of its dv rows (a quarter of a row each) instead of every dv-th entry of whole rows
+    const uint32_t S4 = (uint32_t)(a.S >> 2);
+    auto tp = [&](uint32_t sck) { return (sck & 3u) * S4 + (sck >> 2); };
     const unsigned long long sid = a.sid0 + blockIdx.x;
     const uint32_t s_lo = (uint32_t)sid, s_hi = (uint32_t)(sid >> 32);
 
@@ -231,11 +235,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
                 gkey[at] = make_uint2(k, (uint32_t)s);
                 wlist[atomicAdd(&scal[S_WL], 1)] = make_uint2(k, (uint32_t)s | (g0 << 16));
             }
-            if (q * 4 + 3 < S && (S & 3) == 0) {
-                *reinterpret_cast<uint2 *>(dst + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
-            } else {
-                for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[q * 4 + u] = (uint16_t)c4[u];
-            }
+            for (int u = 0; u < 4; u++) if (q * 4 + u < S) dst[tp((uint32_t)(q * 4 + u))] = (uint16_t)c4[u];
         }
         __syncthreads();
         STAMP(9);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
 #pragma unroll
                     for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
                 }
-                dst[s] = cn_of(rank);
+                dst[tp(s)] = cn_of(rank);
             }
         }
         __syncthreads();
@@ -409,7 +409,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         if (scal[S_OVF]) { __syncthreads(); return false; }
         // the stage is the position's sockets in rank order = the CN -> socket rows; its inverse is the socket -> CN row, built
         // over the counters (done with) so that both leave for the blob as whole lines
-        for (int r = tid; r < S; r += kThreads) irow[stage[r]] = cn_of((uint32_t)r);
+        for (int r = tid; r < S; r += kThreads) irow[tp(stage[r])] = cn_of((uint32_t)r);
         __syncthreads();
         STAMP(4);
         {
@@ -440,8 +440,8 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
             for (int w = tid; w < (chunk + 7) / 8; w += kThreads) fill[w] = 0;
             __syncthreads();
             for (int s = tid; s < S; s += kThreads) {
-                const int c = (int)row[s] - c0;
-                if ((unsigned)c < (unsigned)(c1 - c0)) {
+                const int c = (int)row[tp((uint32_t)s)] - c0;
+                if ((unsigned)c < (unsigned)(c1 - c0)) {   // (c: the CN of socket s)
                     const uint32_t sh = (uint32_t)(c & 7) * 4u;
                     const uint32_t k = (atomicAdd(&fill[c >> 3], 1u << sh) >> sh) & 15u;
                     stage[c * a.dc + (int)k] = (uint16_t)s;
@@ -466,7 +466,7 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
         if (a.ext_inter) {                                  // same-input mode: the permutation was drawn on the host
             const uint16_t *src = a.ext_inter + ((size_t)blockIdx.x * (size_t)(a.ext_npos + dv - 1) + (size_t)(cpos - a.ext_pos0)) * S;
             uint16_t *dst = inter_p() + (size_t)(cpos % dv) * S;
-            for (int s = tid; s < S; s += kThreads) dst[s] = src[s];
+            for (int s = tid; s < S; s += kThreads) dst[tp((uint32_t)s)] = src[s];
             __syncthreads();
         } else {
             if constexpr (FUSED) rows_done = rank_fused(cpos);
@@ -521,10 +521,10 @@ __device__ __forceinline__ void stream_gen_body(const Args &a)
             if (dv == 4) {                                  // four independent loads, one 8-byte row store
                 uint32_t loc[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) loc[i] = inter[(size_t)((g + i) & 3) * S + 4 * t + i];
+                for (int i = 0; i < 4; i++) loc[i] = inter[(size_t)((g + i) & 3) * S + (size_t)i * S4 + t];
                 *reinterpret_cast<uint2 *>(vrows + (size_t)t * 4) = make_uint2(loc[0] | (loc[1] << 16), loc[2] | (loc[3] << 16));
             } else {
-                for (int i = 0; i < dv; i++) vrows[(size_t)t * dv + i] = inter[(size_t)((g + i) % dv) * S + dv * t + i];
+                for (int i = 0; i < dv; i++) vrows[(size_t)t * dv + i] = inter[(size_t)((g + i) % dv) * S + tp((uint32_t)(dv * t + i))];
             }
         }
         __syncthreads();
