@@ -22,6 +22,7 @@
 
 namespace {
 
+constexpr int kBuckets = 2048;            // big kernel, fused ranking: straddling buckets listed per position (1200 at N = 10000)
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxDoped = 32;
@@ -29,6 +30,7 @@ constexpr int kMaxDoped = 32;
 struct SArgs {
     int force_wide;             // diagnostics / tests: rank every position of the big kernel by the 16-bit-counter fallback
     int fine;                   // big kernel: nb counter words (4 * nb nibble buckets) instead of nb / 2
+    int fused;                  // big kernel: the ranking with the stage of S sockets in LDS (rank_fused)
     int dv, dc, L, cns_pos, vns_pos, n, S, D, nb, shift, lgchunk, dc_shift, nw;
     int ens, wrapL, pbits;      // ensemble: 0 Olmos chain, 1 tail-biting (stream and CN position wrap at wrapL = L), 2 protograph
     int ndoped;
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(72))) void
 // (Philox is pure VALU).  Only the keys of straddling buckets (stream_bp.hip's fallback has the same ranking) and the ring of dv
 // permutations live in a per-trial slice of the caller's workspace (L2-resident): the straddlers are ranked from a dense
 // worklist, one trip to the L2 per lane, not one per key and wave.
-template <int ROWS, bool ADJ16>
-__global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_big_kernel(const SArgs a, char *ws, size_t ws_stride)
+template <int ROWS, bool ADJ16, bool FUSED>
+__global__ __launch_bounds__(kThreads, FUSED ? 4 : 8) __attribute__((amdgpu_num_sgpr(72))) void sample_philox_big_kernel(const SArgs a, char *ws, size_t ws_stride)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *hist = lds;                                               // nb / 2 words
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
     uint2 *gkey = reinterpret_cast<uint2 *>(base);                      // [S] (key, socket) of straddling buckets' keys, by rank slot
     uint2 *wlist = gkey + S;                                            // [S] the same as a dense list: (key, socket | first rank << 16)
     uint16_t *win = reinterpret_cast<uint16_t *>(wlist + S);            // [dv][S] CN-local id of every socket, by CN position % dv
+    // a row is kept by edge — socket s = dv*t + i at i * vns_pos + t — so that the wiring of a VN position reads vns_pos consecutive
+    // entries of each of its dv rows instead of every dv-th entry of whole rows (a quarter of the lines)
+    const uint32_t Sdv = (uint32_t)(S / dv);
+    auto tp = [&](uint32_t sck) { return dv == 4 ? (sck & 3u) * Sdv + (sck >> 2) : (sck % (uint32_t)dv) * Sdv + sck / (uint32_t)dv; };
     auto cn_of = [&](uint32_t rank) { return a.dc_shift >= 0 ? rank >> a.dc_shift : rank / (uint32_t)a.dc; };
     auto bucket_base = [&](uint32_t b) -> uint32_t {
         return b >= (uint32_t)nb ? (uint32_t)S : (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
@@ -417,11 +423,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                 gkey[g0 + tsl[s]] = make_uint2(k, (uint32_t)s);
                 wlist[atomicAdd(&wsum[kWaves], 1u)] = make_uint2(k, (uint32_t)s | (g0 << 16));
             }
-            if (q * 4 + 3 < S && (S & 3) == 0) {
-                *reinterpret_cast<uint2 *>(wp + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
-            } else {
-                for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[q * 4 + u] = (uint16_t)c4[u];
-            }
+            for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[tp((uint32_t)(q * 4 + u))] = (uint16_t)c4[u];
         }
         __syncthreads();
         {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
 #pragma unroll
                     for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
                 }
-                wp[s] = (uint16_t)cn_of(rank);
+                wp[tp(s)] = (uint16_t)cn_of(rank);
             }
         }
         __syncthreads();
@@ -517,11 +519,7 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                 gkey[g0 + ((slots >> (4 * u)) & 15u)] = make_uint2(r[u], (uint32_t)s);
                 wlist[atomicAdd(&wsum[kWaves], 1u)] = make_uint2(r[u], (uint32_t)s | (g0 << 16));
             }
-            if (q * 4 + 3 < S && (S & 3) == 0) {
-                *reinterpret_cast<uint2 *>(wp + (size_t)q * 4) = make_uint2(c4[0] | (c4[1] << 16), c4[2] | (c4[3] << 16));
-            } else {
-                for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[q * 4 + u] = (uint16_t)c4[u];
-            }
+            for (int u = 0; u < 4; u++) if (q * 4 + u < S) wp[tp((uint32_t)(q * 4 + u))] = (uint16_t)c4[u];
         }
         __syncthreads();
         {
@@ -539,15 +537,168 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
 #pragma unroll
                     for (int i = 0; i < 4; i++) rank += (m[i].x < k) || (m[i].x == k && m[i].y < s);
                 }
-                wp[s] = (uint16_t)cn_of(rank);
+                wp[tp(s)] = (uint16_t)cn_of(rank);
             }
         }
         __syncthreads();
         return true;
     };
 
+
+    // Round 3, the streaming generator's form (stream_bp.hip, rank_fused) for whole trials: the arrival slots stay in registers
+    // (one nibble per key), so the LDS holds a stage of the position's S sockets beside the 4 * nb nibble counters; first rank +
+    // arrival slot is a rank slot of the key's own: the socket goes to stage[rank slot], the buckets that straddle two CNs are
+    // listed by their first arrivals and ordered one bucket per lane (the keys drawn again from their sockets, once each), and
+    // the socket -> CN row is the inverse of the stage, built over the counters half a row at a time and written out as whole
+    // lines.  Nothing but that row goes through global memory: no records of straddling keys, no partial-line fix-ups.
+    // Returns false (for every thread) when a bucket met a sixteenth key or a list overflowed: rank_wide then ranks the position.
+    auto rank_fused = [&](int p) -> bool {
+        const int nbw = nb, bshift = a.shift - 2;
+        uint16_t *stage = reinterpret_cast<uint16_t *>(tsl);
+        uint32_t *bl = reinterpret_cast<uint32_t *>(stage + ((S + 1) & ~1));      // [kBuckets] first rank | size << 16
+        uint32_t k_lo = a.seed_lo, k_hi = a.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));
+        for (int b = tid; b < nbw; b += kThreads) hist[b] = 0;
+        if (tid == 0) { wsum[kWaves] = 0; wsum[kWaves + 1] = 0; wsum[kWaves + 2] = 0; }
+        __syncthreads();
+        // arrival slots of call tid + k * kThreads: bits 16 (k & 1) of pk[k >> 1]; loops over k are not unrolled (uniform selects)
+        uint32_t pk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, crowded = 0;
+#pragma unroll 1
+        for (int kk = 0; kk * kThreads < ncalls; kk++) {
+            const int q = tid + kk * kThreads;
+            uint32_t mine = 0;
+            if (q < ncalls) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, k_lo, k_hi, r);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (q * 4 + u < S) {
+                        const uint32_t b = r[u] >> bshift, sh = (b & 3u) * 4u;
+                        const uint32_t sl = (atomicAdd(&hist[b >> 2], 1u << sh) >> sh) & 15u;
+                        mine |= sl << (4 * u);
+                        crowded |= sl + 1u;
+                    }
+                }
+            }
+            mine <<= (kk & 1) * 16;
+#pragma unroll
+            for (int h = 0; h < 8; h++) pk[h] |= (kk >> 1) == h ? mine : 0u;
+        }
+        if (crowded & 16u) wsum[kWaves + 1] = 1u;
+        __syncthreads();
+        if (wsum[kWaves + 1] || a.force_wide) { __syncthreads(); return false; }
+        {   // exclusive scan, bank-conflict free: wave w owns words [w, w + 1) * nbw / 16, 64 at a time; first ranks into the high halves
+            const int cw = nbw / kWaves, w0 = wave * cw;
+            uint32_t carry = 0;
+            for (int i0 = 0; i0 < cw; i0 += 64) {
+                const bool on = i0 + lane < cw;
+                const uint32_t x = on ? hist[w0 + i0 + lane] : 0u;
+                const uint32_t sb = (x & 0x0F0Fu) + ((x >> 4) & 0x0F0Fu), ps = (sb + (sb >> 8)) & 0xFFu;
+                const uint32_t inc = wave_inclusive_scan(ps);
+                if (on) hist[w0 + i0 + lane] = x | ((carry + inc - ps) << 16);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+            if (lane == 0) wsum[wave] = carry;
+            __syncthreads();
+            const uint32_t t = lane < kWaves ? wsum[lane] : 0u;
+            const uint32_t tinc = wave_inclusive_scan(t);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(tinc - t), wave) << 16;
+            for (int i0 = 0; i0 < cw; i0 += 64)
+                if (i0 + lane < cw) hist[w0 + i0 + lane] += base;
+        }
+        __syncthreads();
+        auto bucket_of = [&](uint32_t key, uint32_t &g0, uint32_t &cnt) {
+            const uint32_t b = key >> bshift, sh = (b & 3u) * 4u, x = hist[b >> 2], below = x & ((1u << sh) - 1u);
+            g0 = ((x >> 16) + (below & 0xFu) + ((below >> 4) & 0xFu) + ((below >> 8) & 0xFu)) & 0xFFFFu;
+            cnt = (x >> sh) & 0xFu;
+        };
+        bool spill = false;
+#pragma unroll 1
+        for (int kk = 0; kk * kThreads < ncalls; kk++) {
+            const int q = tid + kk * kThreads;
+            uint32_t slots = 0;
+#pragma unroll
+            for (int h = 0; h < 8; h++) slots |= (kk >> 1) == h ? pk[h] : 0u;
+            slots >>= (kk & 1) * 16;
+            if (q < ncalls) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)q, (uint32_t)p, t_lo, t_hi, k_lo, k_hi, r);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int sck = q * 4 + u;
+                    if (sck >= S) continue;
+                    uint32_t g0, cnt;
+                    bucket_of(r[u], g0, cnt);
+                    const uint32_t sl = (slots >> (4 * u)) & 15u;
+                    stage[g0 + sl] = (uint16_t)sck;
+                    if (sl != 0u || !straddles(g0, g0 + cnt)) continue;
+                    const uint32_t at = atomicAdd(&wsum[kWaves], 1u);        // the first key to arrive lists its straddling bucket
+                    if (at < (uint32_t)kBuckets) bl[at] = g0 | (cnt << 16); else spill = true;
+                }
+            }
+        }
+        if (spill) wsum[kWaves + 1] = 1u;
+        __syncthreads();
+        if (wsum[kWaves + 1]) { __syncthreads(); return false; }
+        {   // the straddling buckets, one per lane: keys drawn again (once each) into a scratch over the counters, ordered, the
+            // sockets put back in rank order; a lane owns its bucket's slots of the stage
+            const int nbl = (int)wsum[kWaves];
+            constexpr int kScr = 8192;                                            // 48 KB of the 64 KB of counters
+            uint32_t *kscr = hist;
+            uint16_t *sscr = reinterpret_cast<uint16_t *>(hist + kScr);
+            bool over = false;
+            for (int b = tid; b < nbl; b += kThreads) {
+                const uint32_t g0 = bl[b] & 0xFFFFu, cnt = bl[b] >> 16;
+                const uint32_t base = atomicAdd(&wsum[kWaves + 2], cnt);
+                if (base + cnt > (uint32_t)min(kScr, (nbw * 4 / 6) & ~1)) { over = true; continue; }
+                for (uint32_t m = 0; m < cnt; m++) {
+                    const uint32_t s2 = stage[g0 + m];
+                    uint32_t r2[4];
+                    philox4x32_10(s2 >> 2, (uint32_t)p, t_lo, t_hi, k_lo, k_hi, r2);
+                    kscr[base + m] = (s2 & 2u) ? ((s2 & 1u) ? r2[3] : r2[2]) : ((s2 & 1u) ? r2[1] : r2[0]);
+                    sscr[base + m] = (uint16_t)s2;
+                }
+                for (uint32_t m = 0; m < cnt; m++) {
+                    const uint32_t km = kscr[base + m], sm = sscr[base + m];
+                    uint32_t rank = g0;
+                    for (uint32_t m2 = 0; m2 < cnt; m2++) {
+                        const uint32_t k2 = kscr[base + m2], s2 = sscr[base + m2];
+                        rank += (k2 < km) || (k2 == km && s2 < sm);
+                    }
+                    stage[rank] = (uint16_t)sm;
+                }
+            }
+            if (over) wsum[kWaves + 1] = 1u;
+        }
+        __syncthreads();
+        if (wsum[kWaves + 1]) { __syncthreads(); return false; }
+        // the socket -> CN row (by edge: tp) = the inverse of the stage, half a row at a time over the counters, out as whole lines
+        uint16_t *irow = reinterpret_cast<uint16_t *>(hist);
+        uint16_t *wp = win + (size_t)(p % dv) * S;
+        const uint32_t half = (uint32_t)((S / 2 + 1) & ~1);
+        for (uint32_t h0 = 0; h0 < (uint32_t)S; h0 += half) {
+            for (int r = tid; r < S; r += kThreads) {
+                const uint32_t t = tp(stage[r]) - h0;
+                if (t < half) irow[t] = (uint16_t)cn_of((uint32_t)r);
+            }
+            __syncthreads();
+            const uint32_t cnt16 = min(half, (uint32_t)S - h0);
+            if ((h0 & 1u) == 0u && (cnt16 & 1u) == 0u) {
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(wp + h0);
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(irow);
+                for (uint32_t w = tid; w < cnt16 / 2; w += kThreads) d32[w] = s32[w];
+            } else {
+                for (uint32_t w = tid; w < cnt16; w += kThreads) wp[h0 + w] = irow[w];
+            }
+            __syncthreads();
+        }
+        return true;
+    };
+
     for (int p = 0; p < a.D; p++) {
-        if (!rank_nib(p)) rank_wide(p);
+        bool ranked;
+        if constexpr (FUSED) ranked = rank_fused(p); else ranked = rank_nib(p);
+        if (!ranked) rank_wide(p);
         const int qpos = p - (dv - 1);
         if (qpos >= 0) {
             for (int t = tid; t < a.vns_pos; t += kThreads) {
@@ -555,9 +706,9 @@ __global__ __launch_bounds__(kThreads, 8) __attribute__((amdgpu_num_sgpr(72))) v
                 uint32_t l[8];
                 if (dv == 4) {                              // four independent loads in flight (a run-time dv loop serialises them)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) l[i] = win[(size_t)((qpos + i) & 3) * S + 4 * t + i];
+                    for (int i = 0; i < 4; i++) l[i] = win[(size_t)((qpos + i) & 3) * S + (size_t)i * Sdv + t];
                 } else {
-                    for (int i = 0; i < dv; i++) l[i] = win[(size_t)((qpos + i) % dv) * S + dv * t + i];
+                    for (int i = 0; i < dv; i++) l[i] = win[(size_t)((qpos + i) % dv) * S + (size_t)i * Sdv + t];
                 }
                 if (ADJ16 && dv == 4) {
                     *reinterpret_cast<uint2 *>(a.vn_adj16 + j * 4) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
@@ -657,7 +808,12 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         a.off_gidx = off; off += ((a.S + 1) / 2 + 3) & ~3;
         a.off_win = off;  off += (((size_t)p->dv * a.S + 1) / 2 + 3) & ~3;
     }
-    a.off_wsum = off; off += big ? 32 + (a.S + 15) / 16 * 4 : 32 + kWaves * kWaves;
+    // fused ranking (big, fine): behind the scan scratch a stage of S sockets (2 bytes each; the fallback's byte-wide arrival
+    // slots use the same room) and the list of straddling buckets — 152 KB at N = 10000
+    a.fused = big && a.fine && (a.S + 3) / 4 <= 16 * kThreads;
+    if (const char *v = getenv("SCLDPC_DEBUG_SAMPLER_FUSED")) a.fused = a.fused && atoi(v) != 0;      // A/B, tests
+    if (a.fused && 4u * (size_t)(off + 32 + ((a.S + 1) & ~1) / 2 + kBuckets) > (size_t)scldpc::kMaxLdsBytes) a.fused = 0;
+    a.off_wsum = off; off += big ? (a.fused ? 32 + ((a.S + 1) & ~1) / 2 + kBuckets : 32 + (a.S + 15) / 16 * 4) : 32 + kWaves * kWaves;
     if (const char *v = getenv("SCLDPC_DEBUG_SAMPLER_WIDE")) a.force_wide = atoi(v);          // diagnostics / tests only
     const size_t lds_bytes = 4u * (size_t)off;
     if (lds_bytes > (size_t)scldpc::kMaxLdsBytes)
@@ -671,8 +827,8 @@ int launch(const scldpc_code_params *p, int ensemble, uint64_t seed, uint64_t tr
         if (scratch.query) { *scratch.query = stride * (size_t)ntrials; return SCLDPC_OK; }
         void *ws = nullptr;
         if (int rc = scldpc::take_scratch(who, scratch, stride * (size_t)ntrials, &ws)) return rc;
-        void (*kb)(const SArgs, char *, size_t) = a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16>
-                                                                 : sample_philox_big_kernel<8, ADJ16>;
+        void (*kb)(const SArgs, char *, size_t) = a.fused ? (a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16, true> : sample_philox_big_kernel<8, ADJ16, true>)
+                                                          : (a.nb == 16384 ? sample_philox_big_kernel<16, ADJ16, false> : sample_philox_big_kernel<8, ADJ16, false>);
         if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kb))) return rc_;
         hipLaunchKernelGGL(kb, dim3(ntrials), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a,
                            static_cast<char *>(ws), stride);

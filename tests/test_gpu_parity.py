@@ -305,13 +305,17 @@ def test_ensembles_beyond_the_lds_use_the_global_workspace(E, oracle, L, N, eps)
                                       res["num_blocks_err_exp"], res["num_erasures_p1"]]
 
 
-@pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("L,N,eps,doped", [(8, 5000, 0.47, ()), (6, 10000, 0.46, (2,)), (5, 16384, 0.5, ())])
-def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, monkeypatch, L, N, eps, doped, wide):
-    """More than 8192 sockets per position: the sampler's scratch moves to the workspace; same integers as the twin — through
-    the nibble-wide bucket counters (round 3) and through their 16-bit fallback (forced: SCLDPC_DEBUG_SAMPLER_WIDE)."""
+@pytest.mark.parametrize("path", ["fused", "nibble", "wide", "nibble+wide"])
+@pytest.mark.parametrize("L,N,eps,doped", [(8, 5000, 0.47, ()), (6, 10000, 0.46, (2,)), (5, 16384, 0.5, ()), (5, 2500, 0.4, ())])
+def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, monkeypatch, L, N, eps, doped, path):
+    """More than 8192 sockets per position (sample_philox_big_kernel): same integers as the twin through every ranking the
+    kernel has — fused in LDS (round 3: stage of the position's sockets, straddling buckets ordered per lane, the socket -> CN row
+    as the stage's inverse), nibble-wide counters with the straddlers' records in the workspace (SCLDPC_DEBUG_SAMPLER_FUSED=0),
+    and the 16-bit-counter fallback of either (forced: SCLDPC_DEBUG_SAMPLER_WIDE)."""
     import torch
-    if wide:
+    if "nibble" in path:
+        monkeypatch.setenv("SCLDPC_DEBUG_SAMPLER_FUSED", "0")
+    if "wide" in path:
         monkeypatch.setenv("SCLDPC_DEBUG_SAMPLER_WIDE", "1")
     p = E.make_params(4, 8, L, N)
     po = oracle.Params(4, 8, L, p.cns_pos, p.vns_pos)
