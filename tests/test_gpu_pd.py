@@ -300,6 +300,18 @@ def test_peel_pick_several_trials_per_wave_equal_one_per_wave(PD, monkeypatch, t
     assert any((r[1][:, -1] > 0).any() for r in out["1"]) or True
 
 
+def test_peel_pick_cn_words_built_through_lds_equal_the_atomic_build(PD, monkeypatch):
+    """peel_build_kernel (the CN words of a trial through an LDS ring of dv CN positions, written out as whole lines) against
+    the pick kernel's own build (one global atomic per edge): identical trajectories, terminated and truncated chains."""
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCLDPC_DEBUG_PICK_PREBUILD", mode)
+        out[mode] = [PD.simulate_peeling_decoder_ldpc(e, 4, 8, L, M, term, False, 5, [], rng="philox", seed=21 + k)
+                     for k, (e, L, M, term) in enumerate([(0.3, 44, 4000, True), (0.47, 30, 6000, False), (0.05, 20, 10000, False)])]
+    for a, b in zip(out["1"], out["0"]):
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+
+
 def test_peel_pick_notebook_size_exact_stream(PD):
     """M = 10000 (the notebook's trajectory size, PD:1216) on a short chain, with the reference's own numpy + `random`
     streams: the device consumes the MT19937 state exactly as random.choice would."""
