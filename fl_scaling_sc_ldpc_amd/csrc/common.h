@@ -44,6 +44,9 @@ constexpr int kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU, one workgr
 // the process-global function object: set per call to the launch's own size, two host threads launching the same kernel for
 // different ensembles could lower it between the other thread's set and its launch.  0 or SCLDPC_ERR_HIP.
 int allow_max_lds(const void *kernel);
+// cn_build.hip: the CN words [T][nk] of the dv = 4 chain with 2-byte rows built through an LDS ring; false = not applicable
+bool cn_build_launch(const scldpc_code_params *p, int ntrials, const uint16_t *d_vn_adj16, const uint32_t *d_chan_bits,
+                     uint32_t *d_words, bool deg, void *stream);
 
 // Diagnostics only (tools/ab_occupancy.py): extra bytes of dynamic LDS per workgroup from the environment variable
 // SCLDPC_DEBUG_LDS_PAD_<which>, to measure a kernel at fewer workgroups per CU than its own footprint allows.  0 if unset.

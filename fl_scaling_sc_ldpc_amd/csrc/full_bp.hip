@@ -40,6 +40,7 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
 
 struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
     int dv, L, cns_pos, n, nk, cn_lim, max_it, rows_cap;
+    int prebuilt;                   // WideG: the CN words were built by cn_build.hip (through LDS, not by global atomics)
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     uint32_t *ws;                   // [T][nk] CN words in global memory (WideG only)
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
     auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
 
     // ---- load channel bits, clear CN words -------------------------------------------------
-    for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
+    const bool prebuilt = ST::kGlobal && a.prebuilt;
+    if (!prebuilt) for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
     int ne_local = 0;
     for (int w = tid; w < nw; w += BLOCK) {
         uint32_t x = ch[w];
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
 
     // ---- build: every erased VN adds itself to its dv CNs (TRAJ: every VN also adds to deg) ----
     // Loads are unconditional so that each wave instruction reads 1 KiB contiguous (dv = 4).
-    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {
+    for (int j0 = prebuilt ? n : tid; j0 < n; j0 += 4 * BLOCK) {
         int32_t c[4][8];
         bool er[4];
 #pragma unroll
@@ -350,7 +352,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
     const uint32_t *ch = a.chan + (size_t)trial * nw;
     auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
 
-    for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
+    const bool prebuilt = ST::kGlobal && a.prebuilt;
+    if (!prebuilt) for (int c = tid; c < ST::words(nk); c += BLOCK) cn_state[c] = 0;
     int ne_local = 0;
     for (int w = tid; w < nw; w += BLOCK) {
         uint32_t x = ch[w];
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(72))) void fu
     __syncthreads();
     ne_local = wave_sum(ne_local);
     if (lane == 0 && ne_local) atomicAdd(&scal[S_NE], ne_local);
-    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {                  // build, as in full_bp_kernel
+    for (int j0 = prebuilt ? n : tid; j0 < n; j0 += 4 * BLOCK) {   // build, as in full_bp_kernel
         int32_t c[4][8];
         bool er[4];
 #pragma unroll
@@ -548,6 +551,12 @@ static int launch_full_bp(const scldpc_code_params *p, int32_t ntrials, const vo
     else if (traj) kern = PICK(Wide, true, 1024);
     else kern = PICK(Wide, false, 1024);
 #undef PICK
+    // the workspace's CN words through an LDS ring (cn_build.hip) instead of one global atomic per edge
+    if (global_ws && adj16) {
+        bool pre = true;
+        if (const char *v = getenv("SCLDPC_DEBUG_FULLBP_PREBUILD")) pre = atoi(v) != 0;                     // A/B, tests
+        a.prebuilt = pre && scldpc::cn_build_launch(p, ntrials, static_cast<const uint16_t *>(d_vn_adj), d_chan_bits, a.ws, traj, stream) ? 1 : 0;
+    }
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(block), lds_bytes, static_cast<hipStream_t>(stream), a);

@@ -31,7 +31,7 @@ struct Args {
     int dv, vns_pos, cns_pos, n, ncn, total_size, steps, nw, nd1;     // nd1 = 64-bit words of the degree-1 bitmap
     int rng_mode;                   // 0 = MT19937 state in d_mt, 1 = Philox keyed by (seed, trial0 + trial)
     int ntrials;                    // (multi-trial kernel: the last wave may hold fewer than TPW trials)
-    int prebuilt;                   // (multi-trial kernel) the CN words were built by peel_build_kernel
+    int prebuilt;                   // (multi-trial kernel) the CN words were built by cn_build.hip
     int bshift;                     // a rank-select block covers 2^bshift CNs (64 * 2^(bshift-12) bitmap words)
     uint32_t magic_v, seed_lo, seed_hi;
     unsigned long long trial0;
@@ -248,44 +248,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(SCLDPC_PICK_
     }
 }
 
-
-// ---- the CN words of a trial, built through LDS --------------------------------------------------------------------------------
-// Counting the erased VNs into their CNs from the pick kernel costs one atomic per edge on a random word of the trial's 1 MB of
-// CN words, with 16 384 trials doing so at once: every atomic is a read-modify-write of a cold 128-byte line in DRAM — 680 ms
-// of the 1960 ms of a launch at BASELINE config 3.  The chain's structure keeps it local instead: VN position q only reaches CN
-// positions q .. q + dv - 1.  One 1024-thread workgroup per trial sweeps the VN positions with a ring of dv CN positions in
-// LDS (80 KB at N = 10000): LDS atomics, and a CN position leaves for the workspace — whole lines — once VN position q has been
-// counted into it.  Per trial 4 MB of rows are read and 1 MB of words written, each once.
-__global__ __launch_bounds__(1024) void peel_build_kernel(const Args a)
-{
-    extern __shared__ uint32_t lds[];                                     // [dv][cns_pos] words of the CN positions q .. q + dv - 1
-    const int tid = threadIdx.x, trial = blockIdx.x;
-    const int V = a.vns_pos, C = a.cns_pos, dv = a.dv, L = a.n / V, ncn = a.ncn;
-    const unsigned long long *rows = reinterpret_cast<const unsigned long long *>(a.vn_adj) + (size_t)trial * a.n;
-    const uint32_t *chan = a.chan + (size_t)trial * a.nw;
-    uint32_t *cn = a.ws + (size_t)trial * ncn;
-    for (int i = tid; i < dv * C; i += 1024) lds[i] = 0;
-    __syncthreads();
-    for (int q = 0; q < L + dv - 1; q++) {
-        if (q < L) {
-            for (int t = tid; t < V; t += 1024) {
-                const int j = q * V + t;
-                if ((chan[j >> 5] >> (j & 31)) & 1u) {
-                    const unsigned long long r = rows[j];
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        atomicAdd(&lds[((q + i) & 3) * C + (int)((r >> (16 * i)) & 0xFFFFull)], kCntOne + (uint32_t)j);
-                }
-            }
-            __syncthreads();
-        }
-        // CN position q has all its neighbours (VN positions q - dv + 1 .. q): out, and its slot cleared for CN position q + dv
-        uint32_t *slot = lds + (q & 3) * C;
-        if ((size_t)q * C < (size_t)ncn)
-            for (int c = tid; c < C; c += 1024) { if (q * C + c < ncn) cn[(size_t)q * C + c] = slot[c]; slot[c] = 0; }
-        __syncthreads();
-    }
-}
 
 // ---- several trials per wave ------------------------------------------------------------------------------------------------
 // A pick is a chain of four dependent trips to DRAM (bitmap words, the CN's word, the VN's row, dv returning atomics: the
@@ -538,14 +500,10 @@ static int launch_peel_pick(const scldpc_code_params *p, int32_t ntrials, const 
     if (const char *v = getenv("SCLDPC_DEBUG_PICK_TPW")) tpw = tpw > 1 ? atoi(v) : 1;                 // A/B, tests: 1, 2 or 4
     if (tpw == 2 || tpw == 4) {
         a.ntrials = ntrials;
-        // the CN words through a ring of dv CN positions in LDS (peel_build_kernel) where that ring fits
-        const size_t ring = 4u * (size_t)p->dv * (size_t)p->cns_pos;
-        a.prebuilt = ring <= (size_t)scldpc::kMaxLdsBytes ? 1 : 0;
-        if (const char *v = getenv("SCLDPC_DEBUG_PICK_PREBUILD")) a.prebuilt = a.prebuilt && atoi(v) != 0;      // A/B, tests
-        if (a.prebuilt) {
-            if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(peel_build_kernel))) return rc_;
-            hipLaunchKernelGGL(peel_build_kernel, dim3(ntrials), dim3(1024), ring, static_cast<hipStream_t>(stream), a);
-        }
+        // the CN words through a ring of dv CN positions in LDS (cn_build.hip) where that ring fits
+        bool pre = true;
+        if (const char *v = getenv("SCLDPC_DEBUG_PICK_PREBUILD")) pre = atoi(v) != 0;                      // A/B, tests
+        a.prebuilt = pre && scldpc::cn_build_launch(p, ntrials, static_cast<const uint16_t *>(d_vn_adj), d_chan_bits, a.ws, false, stream) ? 1 : 0;
         kern = tpw == 2 ? peel_pick_multi_kernel<2> : peel_pick_multi_kernel<4>;
         hipLaunchKernelGGL(kern, dim3((ntrials + tpw - 1) / tpw), dim3(kBlock), (size_t)tpw * (64 + 256) * 4, static_cast<hipStream_t>(stream), a);
         SCLDPC_HIP_CHECK(hipGetLastError());

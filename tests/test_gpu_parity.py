@@ -332,6 +332,25 @@ def test_big_ensemble_sampler_equals_cpu_twin(E, oracle, monkeypatch, L, N, eps,
             assert (a == A[t]).all() and (c == Cb[t]).all(), (L, N, adj16, t)
 
 
+@pytest.mark.parametrize("L,N,eps,is_term", [(20, 5000, 0.47, True), (12, 10000, 0.46, False), (30, 2500, 0.48, True)])
+def test_workspace_cn_words_built_through_lds_equal_the_atomic_build(E, monkeypatch, L, N, eps, is_term):
+    """Ensembles whose CN words live in the workspace (N >= 2500, e.g. bp_traj's shipped Def_M = 2500): cn_build.hip builds
+    the words through an LDS ring of dv CN positions instead of one global atomic per edge — every counter, the residuals
+    and the trajectory rows equal the in-kernel build's."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    a, c = E.sample_philox(p, 9, 0, 24, eps, adj16=True)
+    res = {}
+    for pre in ("0", "1"):
+        monkeypatch.setenv("SCLDPC_DEBUG_FULLBP_PREBUILD", pre)
+        res[pre] = [E.full_bp(p, a, c, is_term=is_term, want_erased=True),
+                    E.full_bp(p, a, c, is_term=is_term, rows_cap=1024, want_erased=True)]
+        torch.cuda.synchronize()
+    for x, y in zip(res["0"], res["1"]):
+        assert torch.equal(x["counters"], y["counters"]) and torch.equal(x["erased"], y["erased"])
+        assert (x["rows"] is None and y["rows"] is None) or torch.equal(x["rows"], y["rows"])
+
+
 @pytest.mark.parametrize("name", golden_names(variants=("bpfsw",)))
 def test_classical_window_matches_reference_golden(E, name):
     """decodeBP_SW of BPF:627-897 (classical window) against the real reference's outputs."""
