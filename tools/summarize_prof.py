@@ -24,7 +24,7 @@ WORKLOADS = {"C2": "(4,8) SC-LDPC L=50 N=1000 eps=0.48 full BP unlimited iterati
              "C4": "(4,8) SC-LDPC L=100 N=2000 eps=0.47 decodeBP_SW W=10 I_max=20",
              "C5": "doped (4,8) streaming ensemble N=5000 L=50 W=20 (batch = streams per launch, 16 positions each)"}
 KERNELS = ("sw_ring_kernel", "cn_sockets_kernel", "r1_moments_kernel", "full_bp_small_kernel", "sample_philox_v3_kernel", "sample_philox_v2_kernel", "full_bp_fixpoint_kernel", "full_bp_kernel", "sample_philox_kernel",
-           "sample_philox_big_kernel", "sw_bp_kernel", "accumulate_run_kernel", "peel_pick_multi_kernel", "peel_build_kernel", "peel_pick_kernel", "peel_sweep_kernel",
+           "sample_philox_big_kernel", "sw_bp_kernel", "accumulate_run_kernel", "peel_pick_multi_kernel", "cn_build_kernel", "peel_pick_kernel", "peel_sweep_kernel",
            "stream_bp_kernel", "stream_gen_kernel", "stream_dec_kernel", "accumulate_peel_kernel")
 
 
