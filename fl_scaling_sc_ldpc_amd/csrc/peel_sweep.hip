@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernel_util.h"
 #include "cn_words.h"
+#include <cstdlib>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
     int32_t *out;               // [T][8]: lost, lost_exp, blocks_failed_exp, 0, 0, rounds, 0, #erased
     uint32_t *lost_out;         // optional [T][nw]
     uint32_t *ws;               // [T][ncn] CN words in global memory (ensembles beyond the LDS)
+    int prebuilt;               // … already built by cn_build.hip (through LDS, not by one global atomic per edge)
 };
 
 template <int DV, bool A16, class ST>
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void p
     const uint32_t *ch = a.chan + (size_t)trial * nw;
     auto pos_of = [&](int j) { return (int)__umulhi((uint32_t)j, a.magic_v); };
 
-    for (int c = tid; c < ST::words(ncn); c += kBlock) cn_state[c] = 0;
+    const bool prebuilt = ST::kGlobal && a.prebuilt;
+    if (!prebuilt) for (int c = tid; c < ST::words(ncn); c += kBlock) cn_state[c] = 0;
     auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = pos_of(j); v.t = j - v.pos * a.vns_pos; return v; };
     int ne_local = 0;
     for (int w = tid; w < nw; w += kBlock) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void p
         const uint32_t tot = wave_inclusive_scan((uint32_t)ne_local);
         if (lane == 63 && tot) atomicAdd(&scal[S_NE], (int)tot);
     }
-    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+    for (int j0 = prebuilt ? n : tid; j0 < n; j0 += 4 * kBlock) {
         int32_t c[4][8];
         bool er[4];
 #pragma unroll
@@ -306,6 +309,13 @@ static int launch_peel_sweep(const scldpc_code_params *p, int32_t ntrials, const
                              : (adj16 ? peel_sweep_kernel<0, true, ST> : peel_sweep_kernel<0, false, ST>))
     kern = mode == 0 ? PICK(Packed) : mode == 1 ? PICK(Wide) : PICK(WideG);
 #undef PICK
+    if (global_ws && adj16) {
+        // the first build (every erased VN into its dv CNs) through an LDS ring of dv CN positions — see cn_build.hip; the
+        // second one, over the lost VNs alone, stays in the kernel (a few VNs)
+        bool pre = true;
+        if (const char *v = getenv("SCLDPC_DEBUG_SWEEP_PREBUILD")) pre = atoi(v) != 0;                      // A/B, tests
+        a.prebuilt = pre && scldpc::cn_build_launch(p, ntrials, static_cast<const uint16_t *>(d_vn_adj), d_chan_bits, a.ws, false, stream) ? 1 : 0;
+    }
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);

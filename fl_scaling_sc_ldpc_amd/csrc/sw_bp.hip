@@ -16,6 +16,7 @@
 #include "common.h"
 #include "kernel_util.h"
 #include "cn_words.h"
+#include <cstdlib>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct Layout {             // offsets in 32-bit words into dynamic LDS
 struct Args : Geo {             // Geo: vns_pos, magic_v, magic_c
     int dv, L, cns_pos, n, nk, W, max_it, init_it;
     int classical;                  // 0: square window (BPW:628-912); 1: classical window (BPF:627-897)
+    int prebuilt;                   // WideG: the CN words were built by cn_build.hip (through LDS, not by global atomics)
     Layout lay;
     const void *vn_adj;             // int32 [T][n][dv] or uint16 [T][n][dv] (position-local ids)
     uint32_t *ws;                   // [T][nk] CN words in global memory (G only)
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
     const char *adj = static_cast<const char *>(a.vn_adj) + (size_t)trial * n * dv * (A16 ? 2 : 4);
     const uint32_t *ch = a.chan + (size_t)trial * nw;
 
-    for (int c = tid; c < ST::words(nk); c += kBlock) cn_state[c] = 0;
+    const bool prebuilt = ST::kGlobal && a.prebuilt;
+    if (!prebuilt) for (int c = tid; c < ST::words(nk); c += kBlock) cn_state[c] = 0;
     auto make_vn = [&](int j) { Vn v; v.j = j; v.pos = (int)__umulhi((uint32_t)j, a.magic_v); v.t = j - v.pos * V; return v; };
     for (int w = tid; w < nw; w += kBlock) {
         uint32_t x = ch[w];
@@ -77,7 +80,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(72))) void s
 
     // ---- build the CN words and the per-position erasure counts from the channel ------------
     int nch = 0;
-    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+    if (prebuilt) {
+        // the words are there: only the erasure counts per position are left, 32 VNs per step (V >= 32: a word of channel
+        // bits meets at most two positions)
+        for (int w = tid; w < nw; w += kBlock) {
+            const uint32_t x = S[w];
+            if (!x) continue;
+            nch += __popc(x);
+            const int p0 = (int)__umulhi((uint32_t)(w * 32), a.magic_v), split = (p0 + 1) * V - w * 32;
+            const int lo = split >= 32 ? __popc(x) : __popc(x & ((1u << split) - 1u));
+            if (lo) atomicAdd(&pos_cnt[p0], lo);
+            if (__popc(x) - lo) atomicAdd(&pos_cnt[p0 + 1], __popc(x) - lo);
+        }
+    }
+    for (int j0 = prebuilt ? n : tid; j0 < n; j0 += 4 * kBlock) {
         int32_t c[4][8];
         bool er[4];
 #pragma unroll
@@ -312,6 +328,11 @@ static int launch_sw_bp(const scldpc_code_params *p, int32_t ntrials, const void
                              : (adj16 ? sw_bp_kernel<0, true, ST> : sw_bp_kernel<0, false, ST>))
     kern = packed ? PICK(Packed) : gws ? PICK(WideG) : PICK(Wide);
 #undef PICK
+    if (gws && adj16 && p->vns_pos >= 32) {
+        bool pre = true;
+        if (const char *v = getenv("SCLDPC_DEBUG_SW_PREBUILD")) pre = atoi(v) != 0;                         // A/B, tests
+        a.prebuilt = pre && scldpc::cn_build_launch(p, ntrials, static_cast<const uint16_t *>(d_vn_adj), d_chan_bits, a.ws, false, stream) ? 1 : 0;
+    }
     const size_t lds_bytes = 4u * (size_t)a.lay.total;
     if (int rc_ = scldpc::allow_max_lds(reinterpret_cast<const void *>(kern))) return rc_;
     hipLaunchKernelGGL(kern, dim3(ntrials), dim3(kBlock), lds_bytes, static_cast<hipStream_t>(stream), a);

@@ -312,6 +312,29 @@ def test_peel_pick_cn_words_built_through_lds_equal_the_atomic_build(PD, monkeyp
         assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
 
 
+@pytest.mark.parametrize("L,M,e,term,bounded", [(30, 6000, 0.47, True, True), (24, 10000, 0.49, False, True), (44, 4000, 0.3, False, False)])
+def test_peel_sweep_cn_words_built_through_lds_equal_the_atomic_build(PD, monkeypatch, L, M, e, term, bounded):
+    """scldpc_peel_sweep_device_adj16 with its CN words in the workspace (ensembles beyond the LDS): the first build through
+    cn_build.hip's LDS ring against the kernel's own (one global atomic per edge) — same rows, same lost bits; and one trial
+    against the oracle."""
+    from oracle import pd_oracle as P
+    E = PD.E
+    g = PD._Geometry(4, 8, L, M, term, bounded, [])
+    d_adj, d_ch = E.sample_philox(g.params, 5, 300, 8, e, adj16=True)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCLDPC_DEBUG_SWEEP_PREBUILD", mode)
+        r = E.peel_sweep(g.params, d_adj, d_ch, g.total_size, g.sweep_start, g.lost_lo, g.lost_hi, want_lost=True)
+        res[mode] = (r["out"].cpu().numpy(), r["lost"].cpu().numpy())
+    cols = [0, 1, 2, 7]                              # (column 5 counts the rounds of an order-free peeling)
+    assert (res["1"][0][:, cols] == res["0"][0][:, cols]).all() and (res["1"][1] == res["0"][1]).all()
+    A = E.adj16_to_global(g.params, d_adj[:1].cpu().numpy())
+    bits = E.unpack_bits(d_ch[:1].cpu().numpy(), g.params.n).astype(bool)
+    s = P.sc_ldpc_trial_stats(A[0].astype(np.int64), bits[0], 4, 8, L, M, term, bounded)
+    out = res["1"][0]
+    assert (out[0, 0], out[0, 1], out[0, 2], out[0, 7]) == (s["num_lost"], s["num_lost_exp"], s["blocks_failed_exp"], bits[0].sum())
+
+
 def test_peel_pick_notebook_size_exact_stream(PD):
     """M = 10000 (the notebook's trajectory size, PD:1216) on a short chain, with the reference's own numpy + `random`
     streams: the device consumes the MT19937 state exactly as random.choice would."""

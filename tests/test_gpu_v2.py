@@ -269,6 +269,24 @@ def test_ring_window_decoder_equals_whole_chain_kernel(E, L, N, W, max_it, init_
     assert torch.equal(old["erased"], new["erased"])
 
 
+@pytest.mark.parametrize("L,N,W,max_it,classical,eps", [(100, 2000, 10, 20, False, 0.47), (60, 3300, 8, 12, False, 0.465),
+                                                        (100, 2000, 12, 15, True, 0.47), (60, 3300, 9, 1000000, True, 0.46)])
+def test_whole_chain_window_kernel_cn_words_built_through_lds(E, monkeypatch, L, N, W, max_it, classical, eps):
+    """scldpc_sw_bp_device_adj16 / scldpc_swc_bp_device_adj16 with their CN words in the workspace (chains beyond the LDS):
+    the words built through cn_build.hip's LDS ring (default) against the kernel's own build (one global atomic per edge) —
+    every counter incl. the per-position erasure counts behind them, and the VNerased pattern; V a multiple of 32 and not."""
+    import torch
+    p = E.make_params(4, 8, L, N)
+    a, ch = E.sample_philox(p, 56, 100, 24, eps, adj16=True)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCLDPC_DEBUG_SW_PREBUILD", mode)
+        out[mode] = E.sw_bp(p, a, ch, W, max_it, 0, want_erased=True, classical=classical, ring=False)
+        torch.cuda.synchronize()
+    assert torch.equal(out["1"]["counters"], out["0"]["counters"]) and torch.equal(out["1"]["erased"], out["0"]["erased"])
+    assert int(out["1"]["counters"][:, 7].sum()) == int(E.unpack_bits(ch.cpu().numpy(), p.n).sum())
+
+
 def test_cn_socket_table_is_the_inverse_of_the_vn_table(E):
     import torch
     for L, N in ((10, 10), (12, 1000), (100, 2000)):
