@@ -94,17 +94,18 @@ __global__ __launch_bounds__(BLOCK, PERSIST ? 8 : 7) __attribute__((amdgpu_num_s
     if (lane == 0 && ne_local) atomicAdd(&scal[SC_NE], ne_local);
 
     // ---- build: every erased VN counts itself into its 4 CNs; rows are loaded unconditionally (coalesced 8-B loads) --
-    for (int j0 = tid; j0 < n; j0 += 4 * BLOCK) {
-        uint2 r[4];
-        bool er[4];
+    constexpr int NB = 8;                                                // rows in flight per thread
+    for (int j0 = tid; j0 < n; j0 += NB * BLOCK) {
+        uint2 r[NB];
+        bool er[NB];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NB; u++) {
             const int j = j0 + u * BLOCK;
             er[u] = false;
             if (j < n) { r[u] = vrow[j]; er[u] = (U[j >> 5] >> (j & 31)) & 1u; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NB; u++) {
             const int j = j0 + u * BLOCK;
             if (er[u]) {
                 const int base = (int)__umulhi((uint32_t)j, a.magic_v) * C;
