@@ -28,6 +28,7 @@
 #include "common.h"
 #include "kernel_util.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -529,6 +530,7 @@ int make_args(const scldpc_code_params *p, int32_t is_term, SmArgs *a, int per_c
 constexpr int kBlockSmall = 256;        // threads per trial
 constexpr int kPerCu = 7;               // workgroups per CU the LDS carve aims at (SGPRs <= 96, VGPRs <= 72)
 constexpr int kSwitchWidth = 128;       // frontier entries below which the waves go private
+static_assert(kSwitchWidth <= 64 * (kBlockSmall / 64), "a wave takes at most one frontier entry per lane into its private queue");
 
 }  // namespace
 
@@ -582,6 +584,8 @@ int launch_small(const char *who, bool level, bool sock, const scldpc_code_param
     a.vn_adj16 = d_vn_adj16; a.cn_adj16 = d_cn_adj16; a.chan = d_chan_bits;
     a.counters = d_counters; a.erased_out = d_erased_bits;
     a.kswitch = kSwitchWidth;
+    // A/B only; a wave takes at most one entry per lane into its private queue, so the width is capped at 64 entries per wave
+    if (const char *v = getenv("SCLDPC_DEBUG_DECODER_KSWITCH")) a.kswitch = std::min(atoi(v), 64 * (kBlockSmall / 64));
     a.ntrials = ntrials;
     a.rows = d_rows; a.rows_cap = d_rows ? rows_cap : 0;
     a.max_it = max_it;
