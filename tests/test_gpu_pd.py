@@ -312,7 +312,8 @@ def test_peel_pick_cn_words_built_through_lds_equal_the_atomic_build(PD, monkeyp
         assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
 
 
-@pytest.mark.parametrize("L,M,e,term,bounded", [(30, 6000, 0.47, True, True), (24, 10000, 0.49, False, True), (44, 4000, 0.3, False, False)])
+@pytest.mark.parametrize("L,M,e,term,bounded", [(30, 6000, 0.47, True, True), (24, 10000, 0.49, False, True), (44, 4000, 0.3, False, False),
+                                                (3, 16000, 0.45, True, True), (1, 16000, 0.3, True, True)])     # chains shorter than the ring of dv positions
 def test_peel_sweep_cn_words_built_through_lds_equal_the_atomic_build(PD, monkeypatch, L, M, e, term, bounded):
     """scldpc_peel_sweep_device_adj16 with its CN words in the workspace (ensembles beyond the LDS): the first build through
     cn_build.hip's LDS ring against the kernel's own (one global atomic per edge) — same rows, same lost bits; and one trial

@@ -270,7 +270,8 @@ def test_ring_window_decoder_equals_whole_chain_kernel(E, L, N, W, max_it, init_
 
 
 @pytest.mark.parametrize("L,N,W,max_it,classical,eps", [(100, 2000, 10, 20, False, 0.47), (60, 3300, 8, 12, False, 0.465),
-                                                        (100, 2000, 12, 15, True, 0.47), (60, 3300, 9, 1000000, True, 0.46)])
+                                                        (100, 2000, 12, 15, True, 0.47), (60, 3300, 9, 1000000, True, 0.46),
+                                                        (3, 16000, 2, 7, False, 0.45), (2, 12000, 2, 5, True, 0.5)])
 def test_whole_chain_window_kernel_cn_words_built_through_lds(E, monkeypatch, L, N, W, max_it, classical, eps):
     """scldpc_sw_bp_device_adj16 / scldpc_swc_bp_device_adj16 with their CN words in the workspace (chains beyond the LDS):
     the words built through cn_build.hip's LDS ring (default) against the kernel's own build (one global atomic per edge) —
